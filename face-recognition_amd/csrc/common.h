@@ -1,0 +1,158 @@
+// Shared device/host helpers for libfr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <type_traits>
+
+#include "../../include/fr_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// ---- host side -------------------------------------------------------------------------------
+void fr_set_error(const std::string& msg);
+#define FR_FAIL(code, msg) do { fr_set_error(msg); return (code); } while (0)
+#define FR_HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    fr_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return FR_ERR_HIP; } } while (0)
+#define FR_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+    fr_set_error(std::string("launch ") + name + ": " + hipGetErrorString(e_)); return FR_ERR_HIP; } } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// host fp32 -> bf16 bits, round to nearest even
+static inline uint16_t host_f2bf(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0;
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float host_bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// ---- device side -----------------------------------------------------------------------------
+#define FR_DEV __device__ __forceinline__
+
+FR_DEV float bfbits_to_f(unsigned short v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// Activation element access: T = bf16 (2 B) or float (4 B).  "Vec8" = 8 consecutive channels.
+struct Vec8f { float v[8]; };
+
+FR_DEV Vec8f load8(const bf16* p) {
+    u32x4 r = *reinterpret_cast<const u32x4*>(p);
+    Vec8f o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o.v[2 * i] = __uint_as_float(r[i] << 16);
+        o.v[2 * i + 1] = __uint_as_float(r[i] & 0xFFFF0000u);
+    }
+    return o;
+}
+FR_DEV Vec8f load8(const float* p) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    Vec8f o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o.v[i] = a[i]; o.v[4 + i] = b[i]; }
+    return o;
+}
+FR_DEV unsigned pack2bf(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 t = { (bf16)lo, (bf16)hi };
+    return __builtin_bit_cast(unsigned, t);
+}
+FR_DEV void store8(bf16* p, const Vec8f& x) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = pack2bf(x.v[2 * i], x.v[2 * i + 1]);
+    *reinterpret_cast<u32x4*>(p) = r;
+}
+FR_DEV void store8(float* p, const Vec8f& x) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = x.v[i]; b[i] = x.v[4 + i]; }
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+
+FR_DEV float apply_act(float v, int act, float slope) {
+    switch (act) {
+        case FR_ACT_PRELU:    return v >= 0.f ? v : v * slope;
+        case FR_ACT_HSWISH:   return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+        case FR_ACT_RELU:     return fmaxf(v, 0.f);
+        case FR_ACT_HSIGMOID: return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+        default:              return v;
+    }
+}
+
+// Split 8 fp32 values into bf16 hi and lo fragments: x ~= hi + lo with ~16 mantissa bits.
+FR_DEV void split8(const Vec8f& x, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        bf16 h = (bf16)x.v[i];
+        hi[i] = h;
+        lo[i] = (bf16)(x.v[i] - (float)h);
+    }
+}
+FR_DEV bf16x8 to_frag(const Vec8f& x) {
+    bf16x8 f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (bf16)x.v[i];
+    return f;
+}
+
+// MFMA 32x32x16 output-row permutation used by every GEMM-shaped kernel here: the weight
+// ("A") row i of n-tile t holds output channel  32t + 16*((i>>2)&1) + (i&3) + 4*(i>>3), so that
+// lane half h (lane>>5), accumulator register r holds channel 32t + 16h + r: 16 consecutive
+// channels per lane, i.e. wide NHWC stores.
+static inline int mfma_row_to_cout(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
+
+// Common epilogue arguments of the GEMM-shaped conv kernels.
+struct EpiArgs {
+    const float* bias;      // [cout_pad32] folded bias (zeros when absent)
+    const float* slope;     // [cout_pad32] PReLU slopes (or NULL)
+    const void* residual;   // [M, cout] activation-typed, or NULL
+    void* y;                // [M, cout] activation-typed
+    int cout;
+    int act;
+};
+
+// Store one 32x32 accumulator tile.  Lane: pixel m (row of Y), channels c0 .. c0+15.
+template <typename TOut>
+FR_DEV void epilogue_store(const f32x16& acc, const EpiArgs& e, long m, int c0, bool m_ok) {
+    if (!m_ok) return;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        int c = c0 + 8 * g;
+        if (c >= e.cout) continue;
+        Vec8f v;
+        f32x4 b0 = *reinterpret_cast<const f32x4*>(e.bias + c);
+        f32x4 b1 = *reinterpret_cast<const f32x4*>(e.bias + c + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v.v[i] = acc[8 * g + i] + b0[i]; v.v[4 + i] = acc[8 * g + 4 + i] + b1[i]; }
+        if (e.act == FR_ACT_PRELU) {
+            f32x4 s0 = *reinterpret_cast<const f32x4*>(e.slope + c);
+            f32x4 s1 = *reinterpret_cast<const f32x4*>(e.slope + c + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v.v[i] = v.v[i] >= 0.f ? v.v[i] : v.v[i] * s0[i];
+                v.v[4 + i] = v.v[4 + i] >= 0.f ? v.v[4 + i] : v.v[4 + i] * s1[i];
+            }
+        } else if (e.act != FR_ACT_NONE) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v.v[i] = apply_act(v.v[i], e.act, 0.f);
+        }
+        long off = m * (long)e.cout + c;
+        if (e.residual) {
+            Vec8f r = load8(reinterpret_cast<const TOut*>(e.residual) + off);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
+        }
+        store8(reinterpret_cast<TOut*>(e.y) + off, v);
+    }
+}

@@ -1,0 +1,53 @@
+// Argument structs and host launchers of every kernel in libfr_hip.so.
+#pragma once
+#include "common.h"
+
+// ---- pointwise (1x1) conv / linear as MFMA GEMM:  Y[m][co] = act(sum_k X[m][k] W[co][k] + b) (+R)
+struct PwArgs {
+    const void* x;        // [M, K] activations (bf16 or fp32), row stride K
+    const bf16* w;        // packed fragments [NT][KS][NS][64][8]  (NS = 2 (hi,lo) for fp32 input)
+    const float* se;      // [M/HW, K] per-image channel scale applied to X on load, or NULL
+    EpiArgs e;
+    long M;
+    int K, KS, NT, HW;
+    int chunk_ks;         // k-steps of W staged in LDS at a time
+};
+int launch_pw(bool in_f32, bool out_f32, const PwArgs& a, hipStream_t st);
+// LDS bytes per (n-tile, k-step) = 1024 * NS; used by the planner to pick chunk_ks.
+void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks);
+
+// ---- depthwise KxK conv, NHWC, LDS-staged
+struct DwArgs {
+    const void* x;        // [N,H,W,C]
+    const float* w;       // [K*K][C] folded
+    const float* bias;    // [C]
+    const float* slope;   // [C] or NULL
+    void* y;              // [N,Ho,Wo,C]
+    int N, H, W, C, Ho, Wo, pad, act;
+    int TH, TW, CBV;      // output tile (TW multiple of 4) and channel-vectors (8 ch) per block
+    int tiles_x, tiles_y, cchunks;
+};
+int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st);
+
+// ---- 3x3 stem conv, Cin = 3, fp32 NCHW in -> NHWC out, MFMA with K = 27 (padded to 32)
+struct StemArgs {
+    const float* x;       // [N,3,H,W]
+    const bf16* w;        // packed [NT][2][NS][64][8]
+    EpiArgs e;
+    int N, H, W, Ho, Wo, stride, NT;
+};
+int launch_stem(bool out_f32, const StemArgs& a, hipStream_t st);
+
+// ---- weighted spatial reduction: out[n][c] = sum_p x[n][p][c] * w[p][c] (+ b[c]); w NULL -> 1/P
+struct ReduceArgs {
+    const void* x;        // [N,P,C]
+    const float* w;       // [P][C] or NULL (mean)
+    const float* bias;    // [C] or NULL
+    float* out;           // [N,C] fp32
+    int N, P, C;
+};
+int launch_reduce(bool f32, const ReduceArgs& a, hipStream_t st);
+
+// ---- layout conversion (plan input for non-stem first layers, taps, final non-linear outputs)
+int launch_nchw_to_nhwc(const float* x, void* y, bool y_f32, int N, int C, int H, int W, hipStream_t st);
+int launch_nhwc_to_nchw(const void* x, bool x_f32, float* y, int N, int C, int H, int W, hipStream_t st);

@@ -1,0 +1,448 @@
+// Plan compiler + executor: turns the reference-level layer list (fr_layer_desc, host fp32 tensors
+// straight from a state_dict) into folded/packed device weights and a launch schedule over the
+// HIP kernels.  Replaces nn.Module construction / load_state_dict / forward (inference.py:55-96,
+// :121-122; evaluate.py:179-194).
+#include <math.h>
+#include <memory>
+#include <vector>
+
+#include "kernels.h"
+
+static thread_local std::string g_last_error;
+void fr_set_error(const std::string& msg) { g_last_error = msg; }
+extern "C" const char* fr_last_error(void) { return g_last_error.c_str(); }
+
+namespace {
+
+enum Kind { K_STEM, K_PW, K_DW, K_GDW /*global depthwise (weighted reduce)*/, K_SE, K_LINEAR, K_CONV3 };
+
+struct Layer {
+    int kind = 0;
+    int src = -1, residual = -1;
+    int cin = 0, cout = 0, k = 1, stride = 1, pad = 0, act = 0;
+    int inC = 0, inH = 0, inW = 0;        // input dims
+    int C = 0, H = 0, W = 0;              // output dims
+    bool out_f32 = false;                 // element type of the output buffer
+    bool in_f32 = false;
+    int slot = -1;                        // output slot
+    int slot_pool = -1, slot_hidden = -1; // SE extras (fp32 [N,C], [N,S]); slot = scale [N,C]
+    // device parameters
+    bf16* w_packed = nullptr;             // GEMM-shaped kernels
+    bf16* w_packed2 = nullptr;            // SE fc2
+    float* w_f32 = nullptr;               // dw / gdw tap-major weights
+    float* bias = nullptr;
+    float* bias2 = nullptr;               // SE fc2 bias
+    float* slope = nullptr;
+    int K = 0, KS = 0, NT = 0, chunk_ks = 0;       // GEMM geometry
+    int K2 = 0, KS2 = 0, NT2 = 0, chunk_ks2 = 0;   // SE fc2 geometry
+};
+
+}  // namespace
+
+struct fr_plan {
+    std::vector<Layer> layers;
+    std::vector<size_t> slot_bytes;       // per image
+    std::vector<void*> allocs;
+    int prec = 0, in_c = 0, in_h = 0, in_w = 0;
+    int input_slot = -1;                  // NHWC copy of the network input (non-stem first layers)
+    int device = 0;
+    int launches = 0;
+    bool act_f32() const { return prec == FR_PREC_F32; }
+    size_t act_bytes() const { return prec == FR_PREC_F32 ? 4 : 2; }
+    ~fr_plan() { for (void* p : allocs) (void)hipFree(p); }
+};
+
+namespace {
+
+template <typename T>
+int upload(fr_plan* pl, const std::vector<T>& host, T** dev) {
+    void* p = nullptr;
+    FR_HIP_CHECK(hipMalloc(&p, std::max<size_t>(host.size() * sizeof(T), 16)));
+    pl->allocs.push_back(p);
+    FR_HIP_CHECK(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = reinterpret_cast<T*>(p);
+    return FR_OK;
+}
+
+// Fold BatchNorm into per-output-channel (scale, shift):  y = conv(x)*scale + shift.
+void fold_bn(const fr_layer_desc& d, int cout, std::vector<double>& scale, std::vector<double>& shift) {
+    scale.assign(cout, 1.0);
+    shift.assign(cout, 0.0);
+    for (int c = 0; c < cout; ++c) {
+        const double b = d.bias ? (double)d.bias[c] : 0.0;
+        if (d.bn_weight) {
+            const double s = (double)d.bn_weight[c] / sqrt((double)d.bn_var[c] + (double)d.bn_eps);
+            scale[c] = s;
+            shift[c] = (b - (double)d.bn_mean[c]) * s + (double)d.bn_bias[c];
+        } else {
+            shift[c] = b;
+        }
+    }
+}
+
+// Pack W[cout][K] (row-major, already folded, double) into MFMA "A" fragments
+// [NT][KS][NS][64 lanes][8]: lane (i = lane&31, h = lane>>5), element j = W[32t + perm(i)][16s+8h+j].
+// NS = 2 stores hi = bf16(w) and lo = bf16(w - hi).
+void pack_gemm_weights(const std::vector<double>& W, int cout, int K, int ns, std::vector<uint16_t>& out,
+                       int* KS_out, int* NT_out) {
+    const int KS = cdiv(K, 16), NT = cdiv(cout, 32);
+    out.assign((size_t)NT * KS * ns * 64 * 8, 0);
+    for (int t = 0; t < NT; ++t)
+        for (int s = 0; s < KS; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int co = 32 * t + mfma_row_to_cout(lane & 31);
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * s + 8 * (lane >> 5) + j;
+                    double w = (co < cout && k < K) ? W[(size_t)co * K + k] : 0.0;
+                    const float wf = (float)w;
+                    const uint16_t hi = host_f2bf(wf);
+                    const size_t base = ((((size_t)t * KS + s) * ns) * 64 + lane) * 8 + j;
+                    out[base] = hi;
+                    if (ns == 2) out[base + 64 * 8] = host_f2bf((float)(w - (double)host_bf2f(hi)));
+                }
+            }
+    *KS_out = KS;
+    *NT_out = NT;
+}
+
+std::vector<float> padded(const std::vector<double>& v, int n) {
+    std::vector<float> o(n, 0.f);
+    for (size_t i = 0; i < v.size(); ++i) o[i] = (float)v[i];
+    return o;
+}
+
+int alloc_slot(std::vector<size_t>& sizes, std::vector<char>& busy, size_t need) {
+    int best = -1;
+    for (size_t i = 0; i < sizes.size(); ++i)
+        if (!busy[i] && (best < 0 || sizes[i] > sizes[best])) best = (int)i;
+    if (best < 0) { sizes.push_back(need); busy.push_back(1); return (int)sizes.size() - 1; }
+    if (sizes[best] < need) sizes[best] = need;
+    busy[best] = 1;
+    return best;
+}
+
+int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
+    const bool af32 = pl->act_f32();
+    char where[64];
+    snprintf(where, sizeof where, "layer %d: ", idx);
+    L.src = d.src; L.residual = d.residual; L.act = d.act;
+    if (d.src >= idx || d.residual >= idx || d.src < -1 || d.residual < -1)
+        FR_FAIL(FR_ERR_ARG, std::string(where) + "src/residual must refer to earlier layers");
+    if (d.src < 0) { L.inC = pl->in_c; L.inH = pl->in_h; L.inW = pl->in_w; L.in_f32 = af32; }
+    else { const Layer& s = pl->layers[d.src]; L.inC = s.C; L.inH = s.H; L.inW = s.W; L.in_f32 = s.out_f32; }
+    if (d.act == FR_ACT_PRELU && !d.prelu) FR_FAIL(FR_ERR_ARG, std::string(where) + "PReLU without slopes");
+    if (!d.weight) FR_FAIL(FR_ERR_ARG, std::string(where) + "missing weight");
+
+    if (d.op == FR_OP_CONV) {
+        L.cin = d.cin; L.cout = d.cout; L.k = d.kernel; L.stride = d.stride; L.pad = d.pad;
+        if (d.cin != L.inC) FR_FAIL(FR_ERR_ARG, std::string(where) + "cin does not match the source layer");
+        if (d.kernel < 1 || d.stride < 1 || d.pad < 0) FR_FAIL(FR_ERR_ARG, std::string(where) + "bad conv geometry");
+        L.C = d.cout;
+        L.H = (L.inH + 2 * d.pad - d.kernel) / d.stride + 1;
+        L.W = (L.inW + 2 * d.pad - d.kernel) / d.stride + 1;
+        if (L.H < 1 || L.W < 1) FR_FAIL(FR_ERR_ARG, std::string(where) + "empty output");
+        if (d.cout % 8) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "cout must be a multiple of 8");
+        std::vector<double> scale, shift;
+        fold_bn(d, d.cout, scale, shift);
+        std::vector<double> slope_d;
+        if (d.act == FR_ACT_PRELU) slope_d.assign(d.prelu, d.prelu + d.cout);
+        const int cpad = cdiv(d.cout, 32) * 32;
+        L.out_f32 = af32;
+
+        if (d.groups == 1 && d.kernel == 1) {
+            if (d.stride != 1 || d.pad != 0) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "1x1 conv must be stride 1, pad 0");
+            if (d.cin % 8) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "1x1 conv cin must be a multiple of 8");
+            L.kind = K_PW; L.K = d.cin;
+            std::vector<double> W((size_t)d.cout * d.cin);
+            for (int co = 0; co < d.cout; ++co)
+                for (int k = 0; k < d.cin; ++k) W[(size_t)co * d.cin + k] = (double)d.weight[(size_t)co * d.cin + k] * scale[co];
+            std::vector<uint16_t> packed;
+            pack_gemm_weights(W, d.cout, d.cin, L.in_f32 ? 2 : 1, packed, &L.KS, &L.NT);
+            int rc = upload(pl, packed, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
+            int ntb; pw_pick_tiling(L.in_f32, L.NT, L.KS, &ntb, &L.chunk_ks);
+        } else if (d.groups == 1 && d.kernel == 3 && d.cin == 3) {
+            if (d.src != -1) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "3-channel 3x3 conv must read the network input");
+            if (d.pad != 1 || (d.stride != 1 && d.stride != 2)) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "stem conv needs pad 1, stride 1|2");
+            L.kind = K_STEM; L.K = 27;
+            std::vector<double> W((size_t)d.cout * 27);
+            for (int co = 0; co < d.cout; ++co)
+                for (int k = 0; k < 27; ++k) W[(size_t)co * 27 + k] = (double)d.weight[(size_t)co * 27 + k] * scale[co];
+            std::vector<uint16_t> packed;
+            pack_gemm_weights(W, d.cout, 27, af32 ? 2 : 1, packed, &L.KS, &L.NT);
+            int rc = upload(pl, packed, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
+        } else if (d.groups == d.cin && d.cin == d.cout) {
+            if (d.cin % 8) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "depthwise channels must be a multiple of 8");
+            const int kk = d.kernel * d.kernel;
+            std::vector<float> wt((size_t)kk * d.cout);
+            for (int c = 0; c < d.cout; ++c)
+                for (int t = 0; t < kk; ++t) wt[(size_t)t * d.cout + c] = (float)((double)d.weight[(size_t)c * kk + t] * scale[c]);
+            int rc = upload(pl, wt, &L.w_f32); if (rc) return rc;
+            if (d.pad == 0 && d.kernel == L.inH && d.kernel == L.inW) {
+                if (d.act != FR_ACT_NONE) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "global depthwise conv with activation");
+                L.kind = K_GDW; L.out_f32 = true;
+            } else {
+                if ((d.kernel != 3 && d.kernel != 5) || (d.stride != 1 && d.stride != 2) || d.pad != (d.kernel - 1) / 2)
+                    FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "depthwise conv: k in {3,5}, stride in {1,2}, same padding");
+                L.kind = K_DW;
+            }
+        } else if (d.groups == 1 && d.kernel == 3) {
+            FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "dense 3x3 conv not built yet");
+        } else {
+            FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "conv shape with no kernel");
+        }
+        int rc = upload(pl, padded(shift, cpad), &L.bias); if (rc) return rc;
+        if (d.act == FR_ACT_PRELU) { rc = upload(pl, padded(slope_d, cpad), &L.slope); if (rc) return rc; }
+        if (L.residual >= 0) {
+            const Layer& r = pl->layers[L.residual];
+            if (r.C != L.C || r.H != L.H || r.W != L.W || r.out_f32 != L.out_f32 || r.kind == K_SE)
+                FR_FAIL(FR_ERR_ARG, std::string(where) + "residual shape mismatch");
+            if (L.kind != K_PW && L.kind != K_CONV3) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "residual only on 1x1 / 3x3 dense convs");
+        }
+        if (d.src >= 0 && pl->layers[d.src].kind == K_SE && L.kind != K_PW)
+            FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "the consumer of an SE block must be a 1x1 conv");
+    } else if (d.op == FR_OP_SE) {
+        if (d.src < 0 || !d.weight2 || !d.bias || !d.bias2) FR_FAIL(FR_ERR_ARG, std::string(where) + "SE needs src, fc1/fc2 weights and biases");
+        if (d.cin != L.inC || d.cin % 8 || d.cout % 8) FR_FAIL(FR_ERR_ARG, std::string(where) + "SE channel mismatch");
+        if (pl->layers[d.src].kind == K_SE) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "SE of SE");
+        L.kind = K_SE; L.cin = d.cin; L.cout = d.cout;
+        L.C = L.inC; L.H = L.inH; L.W = L.inW; L.out_f32 = L.in_f32;
+        const int C = d.cin, S = d.cout;
+        std::vector<double> W1(d.weight, d.weight + (size_t)S * C), W2(d.weight2, d.weight2 + (size_t)C * S);
+        std::vector<uint16_t> p1, p2;
+        pack_gemm_weights(W1, S, C, 2, p1, &L.KS, &L.NT);  L.K = C;
+        pack_gemm_weights(W2, C, S, 2, p2, &L.KS2, &L.NT2); L.K2 = S;
+        int rc = upload(pl, p1, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
+        rc = upload(pl, p2, reinterpret_cast<uint16_t**>(&L.w_packed2)); if (rc) return rc;
+        int ntb;
+        pw_pick_tiling(true, L.NT, L.KS, &ntb, &L.chunk_ks);
+        pw_pick_tiling(true, L.NT2, L.KS2, &ntb, &L.chunk_ks2);
+        std::vector<double> b1(d.bias, d.bias + S), b2(d.bias2, d.bias2 + C);
+        rc = upload(pl, padded(b1, cdiv(S, 32) * 32), &L.bias); if (rc) return rc;
+        rc = upload(pl, padded(b2, cdiv(C, 32) * 32), &L.bias2); if (rc) return rc;
+    } else if (d.op == FR_OP_LINEAR) {
+        if (d.src < 0) FR_FAIL(FR_ERR_ARG, std::string(where) + "Linear needs a source layer");
+        const Layer& s = pl->layers[d.src];
+        if (s.kind == K_SE) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "Linear after SE");
+        const int HW = s.H * s.W, K = s.C * HW;
+        if (d.cin != K) FR_FAIL(FR_ERR_ARG, std::string(where) + "in_features does not match the flattened source");
+        if (K % 8 || d.cout % 8) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "Linear features must be multiples of 8");
+        L.kind = K_LINEAR; L.cin = K; L.cout = d.cout; L.K = K;
+        L.C = d.cout; L.H = 1; L.W = 1; L.out_f32 = true;
+        std::vector<double> scale, shift;
+        fold_bn(d, d.cout, scale, shift);
+        // NCHW flatten index c*HW + p  ->  NHWC index p*C + c   (models/sphereface.py:126-127)
+        std::vector<double> W((size_t)d.cout * K);
+        for (int o = 0; o < d.cout; ++o)
+            for (int c = 0; c < s.C; ++c)
+                for (int p = 0; p < HW; ++p)
+                    W[(size_t)o * K + (size_t)p * s.C + c] = (double)d.weight[(size_t)o * K + (size_t)c * HW + p] * scale[o];
+        std::vector<uint16_t> packed;
+        pack_gemm_weights(W, d.cout, K, L.in_f32 ? 2 : 1, packed, &L.KS, &L.NT);
+        int rc = upload(pl, packed, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
+        int ntb; pw_pick_tiling(L.in_f32, L.NT, L.KS, &ntb, &L.chunk_ks);
+        rc = upload(pl, padded(shift, cdiv(d.cout, 32) * 32), &L.bias); if (rc) return rc;
+        if (d.act == FR_ACT_PRELU) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "PReLU after Linear");
+        if (d.residual >= 0) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "residual after Linear");
+    } else {
+        FR_FAIL(FR_ERR_ARG, std::string(where) + "unknown op");
+    }
+    return FR_OK;
+}
+
+size_t layer_out_bytes(const Layer& L) {           // per image
+    return (size_t)L.C * L.H * L.W * (L.out_f32 ? 4 : 2);
+}
+
+}  // namespace
+
+extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int in_h, int in_w,
+                              int precision, fr_plan** out_plan) {
+    if (!descs || n <= 0 || !out_plan || in_c <= 0 || in_h <= 0 || in_w <= 0)
+        FR_FAIL(FR_ERR_ARG, "fr_plan_create: bad arguments");
+    if (precision != FR_PREC_BF16 && precision != FR_PREC_F32) FR_FAIL(FR_ERR_ARG, "fr_plan_create: bad precision");
+    std::unique_ptr<fr_plan> pl(new fr_plan);
+    pl->prec = precision; pl->in_c = in_c; pl->in_h = in_h; pl->in_w = in_w;
+    FR_HIP_CHECK(hipGetDevice(&pl->device));
+    pl->layers.reserve(n);
+    for (int i = 0; i < n; ++i) {
+        Layer L;
+        int rc = build_layer(pl.get(), descs[i], i, L);
+        if (rc) return rc;
+        pl->layers.push_back(L);
+    }
+    // ---- buffer slots by liveness ----
+    std::vector<int> last_use(n, -1);
+    bool need_input_copy = false;
+    int input_last_use = -1;
+    for (int i = 0; i < n; ++i) {
+        const Layer& L = pl->layers[i];
+        auto touch = [&](int j) {
+            if (j < 0) return;
+            last_use[j] = std::max(last_use[j], i);
+            if (pl->layers[j].kind == K_SE) last_use[pl->layers[j].src] = std::max(last_use[pl->layers[j].src], i);
+        };
+        touch(L.src); touch(L.residual);
+        if (L.src < 0 && L.kind != K_STEM) { need_input_copy = true; input_last_use = i; }
+        if (L.residual == -1 && false) {}
+    }
+    last_use[n - 1] = n;   // final output stays live
+    std::vector<size_t>& sizes = pl->slot_bytes;
+    std::vector<char> busy;
+    if (need_input_copy) pl->input_slot = alloc_slot(sizes, busy, (size_t)in_c * in_h * in_w * pl->act_bytes());
+    int launches = need_input_copy ? 1 : 0;
+    for (int i = 0; i < n; ++i) {
+        Layer& L = pl->layers[i];
+        if (L.kind == K_SE) {
+            L.slot_pool = alloc_slot(sizes, busy, (size_t)L.cin * 4);
+            L.slot_hidden = alloc_slot(sizes, busy, (size_t)L.cout * 4);
+            L.slot = alloc_slot(sizes, busy, (size_t)L.cin * 4);
+            launches += 3;
+        } else {
+            L.slot = alloc_slot(sizes, busy, layer_out_bytes(L));
+            launches += 1;
+        }
+        if (L.kind == K_SE) { busy[L.slot_pool] = 0; busy[L.slot_hidden] = 0; }
+        for (int j = 0; j < i; ++j)
+            if (last_use[j] == i) busy[pl->layers[j].slot] = 0;
+        if (last_use[i] < 0) busy[L.slot] = 0;            // dead output (only reachable through taps)
+        if (need_input_copy && input_last_use == i) busy[pl->input_slot] = 0;
+    }
+    pl->launches = launches + (pl->layers.back().kind == K_LINEAR ? 0 : 1);
+    *out_plan = pl.release();
+    return FR_OK;
+}
+
+extern "C" int fr_plan_destroy(fr_plan* plan) {
+    delete plan;
+    return FR_OK;
+}
+
+extern "C" int fr_plan_workspace_bytes(const fr_plan* plan, int batch, size_t* out_bytes) {
+    if (!plan || batch <= 0 || !out_bytes) FR_FAIL(FR_ERR_ARG, "fr_plan_workspace_bytes: bad arguments");
+    size_t total = 0;
+    for (size_t s : plan->slot_bytes) total += align_up(s * (size_t)batch, 256);
+    *out_bytes = total + 256;
+    return FR_OK;
+}
+
+extern "C" int fr_plan_layer_dims(const fr_plan* plan, int layer, int* c, int* h, int* w) {
+    if (!plan || layer < 0 || layer >= (int)plan->layers.size()) FR_FAIL(FR_ERR_ARG, "fr_plan_layer_dims: bad layer");
+    const Layer& L = plan->layers[layer];
+    if (c) *c = L.C; if (h) *h = L.H; if (w) *w = L.W;
+    return FR_OK;
+}
+
+extern "C" int fr_plan_num_launches(const fr_plan* plan) { return plan ? plan->launches : FR_ERR_ARG; }
+
+extern "C" int fr_embed_tap(const fr_plan* plan, const float* x, int batch, float* out,
+                            void* workspace, size_t workspace_bytes, void* stream,
+                            int tap_layer, float* tap_out) {
+    if (!plan || !x || !out || batch <= 0) FR_FAIL(FR_ERR_ARG, "fr_embed: bad arguments");
+    size_t need = 0;
+    fr_plan_workspace_bytes(plan, batch, &need);
+    if (!workspace || workspace_bytes < need) FR_FAIL(FR_ERR_WORKSPACE, "fr_embed: workspace too small");
+    if (tap_layer >= (int)plan->layers.size() || (tap_layer >= 0 && !tap_out)) FR_FAIL(FR_ERR_ARG, "fr_embed: bad tap");
+    hipStream_t st = (hipStream_t)stream;
+    const int N = batch;
+
+    std::vector<unsigned char*> base(plan->slot_bytes.size());
+    {
+        unsigned char* p = reinterpret_cast<unsigned char*>(align_up((size_t)workspace, 256));
+        for (size_t i = 0; i < base.size(); ++i) { base[i] = p; p += align_up(plan->slot_bytes[i] * (size_t)N, 256); }
+    }
+    const bool af32 = plan->act_f32();
+    const void* in_nhwc = nullptr;
+    if (plan->input_slot >= 0) {
+        int rc = launch_nchw_to_nhwc(x, base[plan->input_slot], af32, N, plan->in_c, plan->in_h, plan->in_w, st);
+        if (rc) return rc;
+        in_nhwc = base[plan->input_slot];
+    }
+    const int nl = (int)plan->layers.size();
+    for (int i = 0; i < nl; ++i) {
+        const Layer& L = plan->layers[i];
+        const bool last = (i == nl - 1);
+        void* y = (last && L.kind == K_LINEAR) ? (void*)out : (void*)base[L.slot];
+        const void* xin = nullptr;
+        const float* se = nullptr;
+        if (L.src < 0) xin = in_nhwc;
+        else if (plan->layers[L.src].kind == K_SE) {
+            const Layer& S = plan->layers[L.src];
+            xin = base[plan->layers[S.src].slot];
+            se = reinterpret_cast<const float*>(base[S.slot]);
+        } else xin = base[plan->layers[L.src].slot];
+        const void* res = L.residual >= 0 ? base[plan->layers[L.residual].slot] : nullptr;
+        int rc = FR_OK;
+        switch (L.kind) {
+            case K_STEM: {
+                StemArgs a{};
+                a.x = x; a.w = L.w_packed;
+                a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act};
+                a.N = N; a.H = L.inH; a.W = L.inW; a.Ho = L.H; a.Wo = L.W; a.stride = L.stride; a.NT = L.NT;
+                rc = launch_stem(L.out_f32, a, st);
+                break;
+            }
+            case K_PW: case K_LINEAR: {
+                PwArgs a{};
+                a.x = xin; a.w = L.w_packed; a.se = se;
+                a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act};
+                a.M = L.kind == K_PW ? (long)N * L.H * L.W : (long)N;
+                a.K = L.K; a.KS = L.KS; a.NT = L.NT; a.HW = L.H * L.W; a.chunk_ks = L.chunk_ks;
+                rc = launch_pw(L.in_f32, L.out_f32, a, st);
+                break;
+            }
+            case K_DW: {
+                DwArgs a{};
+                a.x = xin; a.w = L.w_f32; a.bias = L.bias; a.slope = L.slope; a.y = y;
+                a.N = N; a.H = L.inH; a.W = L.inW; a.C = L.C; a.Ho = L.H; a.Wo = L.W; a.pad = L.pad; a.act = L.act;
+                rc = launch_dw(L.in_f32, L.k, L.stride, a, st);
+                break;
+            }
+            case K_GDW: {
+                ReduceArgs a{xin, L.w_f32, L.bias, reinterpret_cast<float*>(y), N, L.inH * L.inW, L.C};
+                rc = launch_reduce(L.in_f32, a, st);
+                break;
+            }
+            case K_SE: {
+                float* pool = reinterpret_cast<float*>(base[L.slot_pool]);
+                float* hid = reinterpret_cast<float*>(base[L.slot_hidden]);
+                ReduceArgs r{xin, nullptr, nullptr, pool, N, L.H * L.W, L.C};
+                rc = launch_reduce(L.in_f32, r, st);
+                if (rc) break;
+                PwArgs a{};
+                a.x = pool; a.w = L.w_packed; a.se = nullptr;
+                a.e = EpiArgs{L.bias, nullptr, nullptr, hid, L.cout, FR_ACT_RELU};
+                a.M = N; a.K = L.K; a.KS = L.KS; a.NT = L.NT; a.HW = 1; a.chunk_ks = L.chunk_ks;
+                rc = launch_pw(true, true, a, st);
+                if (rc) break;
+                PwArgs b{};
+                b.x = hid; b.w = L.w_packed2; b.se = nullptr;
+                b.e = EpiArgs{L.bias2, nullptr, nullptr, y, L.cin, FR_ACT_HSIGMOID};
+                b.M = N; b.K = L.K2; b.KS = L.KS2; b.NT = L.NT2; b.HW = 1; b.chunk_ks = L.chunk_ks2;
+                rc = launch_pw(true, true, b, st);
+                break;
+            }
+            default: FR_FAIL(FR_ERR_UNSUPPORTED, "fr_embed: kernel kind not built");
+        }
+        if (rc) return rc;
+        if (i == tap_layer) {
+            if (L.kind == K_SE) {           // tap of an SE block = its per-image scale [N,C]
+                FR_HIP_CHECK(hipMemcpyAsync(tap_out, y, (size_t)N * L.C * 4, hipMemcpyDeviceToDevice, st));
+            } else if (L.kind == K_LINEAR || L.kind == K_GDW) {
+                if (y != (void*)tap_out) FR_HIP_CHECK(hipMemcpyAsync(tap_out, y, (size_t)N * L.C * 4, hipMemcpyDeviceToDevice, st));
+            } else {
+                rc = launch_nhwc_to_nchw(y, L.out_f32, tap_out, N, L.C, L.H, L.W, st);
+                if (rc) return rc;
+            }
+        }
+        if (last && L.kind != K_LINEAR) {
+            if (L.kind == K_GDW || L.kind == K_SE) FR_HIP_CHECK(hipMemcpyAsync(out, y, (size_t)N * L.C * 4, hipMemcpyDeviceToDevice, st));
+            else { rc = launch_nhwc_to_nchw(y, L.out_f32, out, N, L.C, L.H, L.W, st); if (rc) return rc; }
+        }
+    }
+    return FR_OK;
+}
+
+extern "C" int fr_embed(const fr_plan* plan, const float* x, int batch, float* out,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    return fr_embed_tap(plan, x, batch, out, workspace, workspace_bytes, stream, -1, nullptr);
+}

@@ -1,0 +1,160 @@
+"""Mirror of the reference's inference.py entry points (same names, arguments, return types and
+error behaviour) on top of the HIP plan.  Citations: /root/reference/inference.py."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from pathlib import Path
+from typing import Callable, Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import models as M
+
+_CTORS: Dict[str, Callable[[int], torch.nn.Module]] = {
+    "sphere20": lambda e: M.sphere20(embedding_dim=e, in_channels=3),
+    "sphere36": lambda e: M.sphere36(embedding_dim=e, in_channels=3),
+    "sphere64": lambda e: M.sphere64(embedding_dim=e, in_channels=3),
+    "mobilenetv1": lambda e: M.MobileNetV1(embedding_dim=e),
+    "mobilenetv2": lambda e: M.MobileNetV2(embedding_dim=e),
+    "mobilenetv3_small": lambda e: M.mobilenet_v3_small(embedding_dim=e),
+    "mobilenetv3_large": lambda e: M.mobilenet_v3_large(embedding_dim=e),
+}
+
+
+def get_network(model_name: str) -> torch.nn.Module:
+    """inference.py:29-52.  (Builds only the requested backbone; the reference instantiates all
+    seven and returns one -- same result, ValueError for unknown names with the same message.)"""
+    if model_name not in _CTORS:
+        raise ValueError(f"Unsupported network '{model_name}'! Available options: {list(_CTORS.keys())}")
+    return _CTORS[model_name](512)
+
+
+def load_model(model_name: str, model_path: str, device: torch.device = None) -> torch.nn.Module:
+    """inference.py:55-96: accepts a full ``.ckpt`` dict (key 'model', optional 'args') or a bare
+    state_dict; strict load; ``.to(device).eval()``; every failure becomes RuntimeError."""
+    try:
+        # weights_only=False as in the reference (:60): .ckpt files pickle an argparse.Namespace.
+        checkpoint = torch.load(model_path, map_location="cpu", weights_only=False)
+        if "model" in checkpoint:
+            embedding_dim = getattr(checkpoint["args"], "embedding_dim", 512) if "args" in checkpoint else 512
+            if model_name not in _CTORS:
+                raise ValueError(f"Unsupported network '{model_name}'")
+            model = _CTORS[model_name](embedding_dim)
+            model.load_state_dict(checkpoint["model"])
+        else:
+            model = get_network(model_name)
+            model.load_state_dict(checkpoint)
+        model.to(device).eval()
+    except Exception as e:
+        raise RuntimeError(f"Error loading model '{model_name}' from {model_path}: {e}")
+    return model
+
+
+def _transform(img) -> torch.Tensor:
+    """Resize((112,112)) -> ToTensor -> Normalize(0.5, 0.5) on a PIL image (inference.py:102-106).
+    torchvision resizes PIL inputs with PIL's bilinear filter, which is what is called here."""
+    from PIL import Image
+    if img.size != (112, 112):
+        img = img.resize((112, 112), Image.BILINEAR)
+    a = np.asarray(img, dtype=np.uint8)
+    t = torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1).to(torch.float32).div(255)
+    return (t - 0.5) / 0.5
+
+
+def get_transform():
+    """inference.py:98-106."""
+    return _transform
+
+
+def extract_features(model, device, img_path: str) -> np.ndarray:
+    """inference.py:109-123: one image -> raw (un-normalised) embedding, np.float32 [512]."""
+    from PIL import Image
+    transform = get_transform()
+    try:
+        img = Image.open(img_path).convert("RGB")
+    except Exception as e:
+        raise FileNotFoundError(f"Error opening image {img_path}: {e}")
+    tensor = transform(img).unsqueeze(0).to(device)
+    with torch.no_grad():
+        features = model(tensor).squeeze().cpu().numpy()
+    return features
+
+
+def embed_images(model, device, images: Sequence[np.ndarray], batch_size: int = 1024) -> torch.Tensor:
+    """Batched extraction: uint8 [112,112,3] arrays -> fp32 [n,512] on
+    ``device``.  Same arithmetic as extract_features per image, large batches on the GPU."""
+    outs: List[torch.Tensor] = []
+    with torch.no_grad():
+        for i in range(0, len(images), batch_size):
+            a = np.stack(images[i:i + batch_size])
+            t = torch.from_numpy(a).to(device).permute(0, 3, 1, 2).to(torch.float32).div(255)
+            outs.append(model((t - 0.5) / 0.5))
+    return torch.cat(outs) if outs else torch.empty(0, 512, device=device)
+
+
+def extract_batch_embeddings(model, device, image_folder: str, output_file: str = "assets/embeddings.json") -> dict:
+    """inference.py:125-164: folder -> {filename: [floats]}, saved as JSON (indent 2).  Per-file
+    errors are printed and skipped, as in the reference (:155-156)."""
+    image_extensions = (".jpg", ".jpeg", ".png", ".bmp", ".tiff")
+    image_files = []
+    for ext in image_extensions:
+        image_files.extend(Path(image_folder).glob(f"*{ext}"))
+        image_files.extend(Path(image_folder).glob(f"*{ext.upper()}"))
+    embeddings_dict = {}
+    print(f"Extracting embeddings from {len(image_files)} images...")
+    for img_path in image_files:
+        try:
+            embedding = extract_features(model, device, str(img_path))
+            embeddings_dict[img_path.name] = embedding.tolist()
+            print(f"✓ Processed: {img_path.name}")
+        except Exception as e:
+            print(f"✗ Error processing {img_path.name}: {e}")
+    os.makedirs(os.path.dirname(output_file), exist_ok=True)
+    with open(output_file, "w") as f:
+        json.dump(embeddings_dict, f, indent=2)
+    print(f"\nEmbeddings saved to: {output_file}")
+    return embeddings_dict
+
+
+def cosine_pairs(a: torch.Tensor, b: torch.Tensor, eps: float = 0.0, threshold: float = 0.35
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Device pair scoring (fr_cosine_pairs): a,b fp32 [P,d] on the GPU -> (sim fp32 [P], same bool [P]).
+    eps=0 is utils/face_utils.py:86; eps=1e-5 is evaluate.py:554; decision = float64(sim) > threshold."""
+    if not (a.is_cuda and b.is_cuda):
+        raise RuntimeError("cosine_pairs needs GPU tensors: the hot path has no CPU fallback")
+    a = a.to(torch.float32).contiguous()
+    b = b.to(torch.float32).contiguous()
+    if a.shape != b.shape or a.dim() != 2:
+        raise ValueError("cosine_pairs: expected two [P,d] tensors of equal shape")
+    P, d = a.shape
+    sim = torch.empty(P, dtype=torch.float32, device=a.device)
+    dec = torch.empty(P, dtype=torch.uint8, device=a.device)
+    if P:
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.lib().fr_cosine_pairs(a.data_ptr(), b.data_ptr(), P, d, C.c_float(eps), C.c_double(threshold),
+                                                  sim.data_ptr(), dec.data_ptr(),
+                                                  torch.cuda.current_stream(a.device).cuda_stream), "fr_cosine_pairs")
+    return sim, dec.bool()
+
+
+def compute_similarity(feat1: np.ndarray, feat2: np.ndarray) -> np.float32:
+    """utils/face_utils.py:74-87 semantics (cosine, no epsilon, np.float32 result), computed by
+    fr_cosine_pairs on the GPU."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    a = torch.from_numpy(np.ascontiguousarray(feat1, dtype=np.float32).ravel()[None]).to(dev)
+    b = torch.from_numpy(np.ascontiguousarray(feat2, dtype=np.float32).ravel()[None]).to(dev)
+    sim, _ = cosine_pairs(a, b, eps=0.0)
+    return np.float32(sim.cpu().numpy()[0])
+
+
+def compare_faces(model, device, img1_path: str, img2_path: str, threshold: float = 0.35) -> tuple:
+    """inference.py:167-177."""
+    feat1 = extract_features(model, device, img1_path)
+    feat2 = extract_features(model, device, img2_path)
+    similarity = compute_similarity(feat1, feat2)
+    is_same = similarity > threshold
+    return similarity, is_same

@@ -1,0 +1,140 @@
+/* fr_hip.h -- C ABI of the MI355X-native embed-and-match hot path (libfr_hip.so).
+ *
+ * The reference (CEIA-NoLeakIV/face-recognition) has no FFI: its hot path is `model(tensor)` on a
+ * torch.nn.Module (inference.py:120-122, evaluate.py:189-192), NumPy/torch cosine formulas
+ * (utils/face_utils.py:84-87, evaluate.py:554) and no 1:N search at all.  This header is therefore
+ * the interface a maintainer would bind (ctypes stub shown in INTEGRATION.md) to swap that path
+ * for hand-written gfx950 kernels.  Each entry point names the reference lines it replaces.
+ *
+ * Conventions: plain C, no C++ types or exceptions across the boundary.  Every function returns
+ * 0 on success or a negative fr_status; fr_last_error() returns a thread-local message.  Unless
+ * stated otherwise pointers are DEVICE pointers owned by the caller; the library never allocates
+ * or frees caller outputs; launches are asynchronous on the given hipStream_t (passed as void*,
+ * NULL = default stream).  The only device memory the library owns is the packed weights of a
+ * plan (allocated in fr_plan_create, freed in fr_plan_destroy).
+ */
+#ifndef FR_HIP_H
+#define FR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum fr_status {
+    FR_OK = 0,
+    FR_ERR_ARG = -1,          /* bad argument / inconsistent description */
+    FR_ERR_UNSUPPORTED = -2,  /* layer shape with no kernel */
+    FR_ERR_HIP = -3,          /* HIP runtime error (message has hipGetErrorString) */
+    FR_ERR_WORKSPACE = -4     /* workspace too small */
+} fr_status;
+
+/* Activation storage / arithmetic mode of a plan.
+ * FR_PREC_BF16: activations stored bf16, single bf16 MFMA pass, fp32 accumulate + fp32 epilogue.
+ * FR_PREC_F32 : activations stored fp32; GEMM operands split hi+lo bf16, three MFMA passes
+ *               (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo), fp32 accumulate (~16 mantissa bits). */
+typedef enum fr_precision { FR_PREC_BF16 = 0, FR_PREC_F32 = 1 } fr_precision;
+
+typedef enum fr_op { FR_OP_CONV = 0, FR_OP_SE = 1, FR_OP_LINEAR = 2 } fr_op;
+typedef enum fr_act { FR_ACT_NONE = 0, FR_ACT_PRELU = 1, FR_ACT_HSWISH = 2,
+                      FR_ACT_RELU = 3, FR_ACT_HSIGMOID = 4 } fr_act;
+
+/* One reference layer group, described with HOST pointers to the fp32 tensors exactly as they sit
+ * in the reference state_dict (no folding, no re-layout on the caller's side).
+ *   FR_OP_CONV   Conv2d [+BatchNorm2d] [+PReLU|Hardswish]   (utils/layers.py:15-84, :156-173;
+ *                models/mobilenetv2.py:45-46).  weight [cout, cin/groups, k, k].
+ *   FR_OP_SE     SqueezeExcitation (utils/layers.py:87-122 with Hardsigmoid): cin = channels,
+ *                cout = squeeze channels, weight/bias = fc1 [S,C]/[S], weight2/bias2 = fc2 [C,S]/[C].
+ *                Output = scale * input; its consumer must be a 1x1 conv.
+ *   FR_OP_LINEAR Linear [+BatchNorm1d] on the NCHW-flattened output of `src`
+ *                (utils/layers.py:183-186; models/sphereface.py:84,126-127).  weight [out, in].
+ * src / residual are indices into the descriptor array (-1 = network input / none); the residual
+ * tensor is added after BN and activation (models/mobilenetv3.py:96-97, mobilenetv2.py:55,
+ * sphereface.py:48). */
+typedef struct fr_layer_desc {
+    int32_t op;
+    int32_t src;
+    int32_t residual;
+    int32_t cin, cout;
+    int32_t kernel, stride, pad, groups;
+    int32_t act;
+    const float* weight;
+    const float* bias;        /* NULL if the conv/linear has no bias */
+    const float* bn_weight;   /* gamma; NULL if no BatchNorm follows */
+    const float* bn_bias;
+    const float* bn_mean;
+    const float* bn_var;
+    float bn_eps;
+    const float* prelu;       /* [cout] slopes when act == FR_ACT_PRELU */
+    const float* weight2;     /* SE only */
+    const float* bias2;       /* SE only */
+} fr_layer_desc;
+
+typedef struct fr_plan fr_plan;
+
+const char* fr_last_error(void);
+
+/* Replaces: nn.Module construction + load_state_dict + .to(device).eval() (inference.py:55-96).
+ * Folds BatchNorm (w' = w*g/sqrt(v+eps), b' = (b-m)*g/sqrt(v+eps)+beta, in double), packs weights
+ * into MFMA fragment order / NHWC tap-major order, permutes Linear columns from NCHW-flatten to
+ * NHWC order, uploads them to the CURRENT device.  Network input is fp32 NCHW [batch,in_c,in_h,in_w]. */
+int fr_plan_create(const fr_layer_desc* layers, int n_layers, int in_c, int in_h, int in_w,
+                   int precision, fr_plan** out_plan);
+int fr_plan_destroy(fr_plan* plan);
+
+/* Bytes of caller-provided device scratch needed by fr_embed for `batch` images. */
+int fr_plan_workspace_bytes(const fr_plan* plan, int batch, size_t* out_bytes);
+/* Output shape of layer `layer` (c,h,w); LINEAR / SE report (features,1,1). */
+int fr_plan_layer_dims(const fr_plan* plan, int layer, int* c, int* h, int* w);
+/* Number of kernel launches one fr_embed call issues (diagnostics). */
+int fr_plan_num_launches(const fr_plan* plan);
+
+/* Replaces: `model(tensor)` under torch.no_grad() (inference.py:121-122, evaluate.py:191-192).
+ * x: fp32 NCHW [batch,in_c,in_h,in_w].  out: fp32; if the last layer is LINEAR it is
+ * [batch,out_features], otherwise the last activation as NCHW fp32.  Raw, un-normalised, as the
+ * reference backbones return (utils/layers.py:188-191). */
+int fr_embed(const fr_plan* plan, const float* x, int batch, float* out,
+             void* workspace, size_t workspace_bytes, void* stream);
+/* Same, and additionally writes the output of layer `tap_layer` as fp32 NCHW to tap_out
+ * (parity tests of intermediate blocks; no reference counterpart beyond forward hooks). */
+int fr_embed_tap(const fr_plan* plan, const float* x, int batch, float* out,
+                 void* workspace, size_t workspace_bytes, void* stream,
+                 int tap_layer, float* tap_out);
+
+/* L2-normalise rows: y = x / max(||x||, tiny); norms[n] optional (may be NULL).  The reference
+ * normalises inside its similarity formulas only; this is the gallery/query preparation step. */
+int fr_l2norm(const float* x, float* y, float* norms, int n, int d, void* stream);
+/* fp32 rows -> L2-normalised bf16 rows (gallery / query format of fr_topk_search). */
+int fr_l2norm_bf16(const float* x, uint16_t* y, int n, int d, void* stream);
+
+/* Replaces: compute_similarity (utils/face_utils.py:84-87; eps = 0) and the LFW pair score
+ * f1.dot(f2)/(f1.norm()*f2.norm()+1e-5) (evaluate.py:554; eps = 1e-5), plus the decision
+ * `float64(sim) > threshold` (evaluate.py:205-206, inference.py:175).
+ * a,b: fp32 [pairs,d]; out_sim fp32 [pairs]; out_dec uint8 [pairs] or NULL. */
+int fr_cosine_pairs(const float* a, const float* b, int pairs, int d, float eps, double threshold,
+                    float* out_sim, uint8_t* out_dec, void* stream);
+
+/* Synthetic gallery / query rows, bit-identical to
+ * oracle/search.py.  Writes rows [row0,row0+nrows) of the global set as L2-normalised bf16.
+ * plant_seed/n_plant/n_gallery_total: planted matches (n_plant = 0 for queries). */
+int fr_synth_rows(uint16_t* out, uint64_t seed, int64_t row0, int64_t nrows, int dim,
+                  uint64_t plant_seed, int64_t n_plant, int64_t n_gallery_total, void* stream);
+
+/* 1:N cosine search (no reference counterpart; definitional oracle in oracle/search.py).
+ * q bf16 [Q,d] and g bf16 [G,d] are L2-normalised rows; scores = q @ g^T on MFMA, exact top-k
+ * per query (k <= 8), ties to the lower index.  out_scores fp32 [Q,k] descending, out_idx int64
+ * [Q,k] = local row + idx_offset.  workspace: fr_topk_workspace_bytes(Q,G,k) bytes. */
+int fr_topk_workspace_bytes(int64_t Q, int64_t G, int k, size_t* out_bytes);
+int fr_topk_search(const uint16_t* q, const uint16_t* g, int64_t Q, int64_t G, int d, int k,
+                   int64_t idx_offset, float* out_scores, int64_t* out_idx,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* Merge P per-shard results (scores [P,Q,k], idx [P,Q,k], e.g. after an RCCL all-gather) into the
+ * global top-k [Q,k]; deterministic: descending score, ties to the lower global index. */
+int fr_topk_merge(const float* scores, const int64_t* idx, int P, int64_t Q, int k,
+                  float* out_scores, int64_t* out_idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FR_HIP_H */

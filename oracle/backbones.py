@@ -306,7 +306,7 @@ def unit_names(net: nn.Module) -> List[str]:
     for name, m in net.named_modules():
         if isinstance(m, (SqueezeExcite, _LinearBlock)):
             out.append(name)
-        elif isinstance(m, nn.Sequential) and len(m) and isinstance(m[0], nn.Conv2d):
+        elif isinstance(m, nn.Sequential) and len(m) and isinstance(m[0], nn.Conv2d) and not name.endswith(".layers"):
             out.append(name)
         elif isinstance(m, nn.BatchNorm2d) and name.split(".")[-2] == "conv":   # mnv2 project conv's BN
             out.append(name)

@@ -1,0 +1,246 @@
+"""GPU parity tests: the HIP path (through the C ABI of libfr_hip.so) against the CPU oracle and the
+golden vectors captured from the real reference.  Bars: embedding cosine >= 0.9999,
+similarity |delta| <= 1e-3, decisions at 0.35 identical, top-5 indices identical where the score gap
+exceeds 1e-3; integer/bit work (synthetic rows) bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import face_recognition_amd as fr
+from oracle import backbones as ob
+from oracle import scoring as osc
+from oracle import search as osr
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+COS_BAR = 0.9999
+
+
+def cos_rows(a, b):
+    a = np.asarray(a, np.float64).reshape(len(a), -1); b = np.asarray(b, np.float64).reshape(len(b), -1)
+    return (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1) + 1e-300)
+
+
+def product(name, state_dict=None):
+    torch.manual_seed(0)
+    m = fr.get_network(name)
+    if state_dict is not None:
+        m.load_state_dict(state_dict)
+    return m.to(DEV).eval()
+
+
+def layer_report(model, oracle, x, precision):
+    """Per-plan-layer cosine / relative max error against oracle forward hooks."""
+    names = model.layer_names()
+    onames = [n for n in names if n in dict(oracle.named_modules())]
+    _, taps = ob.forward_with_taps(oracle, x, onames)
+    rows = []
+    for i, n in enumerate(names):
+        if n not in taps or isinstance(dict(oracle.named_modules())[n], ob.SqueezeExcite):
+            continue
+        _, t = model.forward_tap(x.to(DEV), i, precision)
+        ref = taps[n].numpy().reshape(len(x), -1)
+        got = t.cpu().numpy().reshape(len(x), -1)
+        rel = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-300)
+        rows.append((i, n, cos_rows(got, ref).min(), rel))
+    return rows
+
+
+@pytest.mark.parametrize("precision,bar,relbar", [("f32", 0.999999, 1e-3), ("bf16", 0.9995, 0.1)])
+@pytest.mark.parametrize("name", ["mobilenetv3_large", "mobilenetv3_small", "mobilenetv2", "mobilenetv1"])
+def test_every_layer_against_oracle_hooks(name, precision, bar, relbar, golden_x):
+    """Each fused unit (conv+BN+act, project+residual, SE-scaled project, GDC) vs the oracle's hook at
+    the same point.  f32 mode must track to ~1e-6; bf16 mode within bf16 rounding accumulation."""
+    x = golden_x[:3]
+    rows = layer_report(product(name), ob.seeded(name, 0), x, precision)
+    bad = [r for r in rows if not (r[2] >= bar and r[3] <= relbar)]
+    msg = "\n".join(f"{i:3d} {n:40s} cos={c:.8f} relmax={e:.3e}" for i, n, c, e in rows)
+    assert not bad, f"{name} {precision}: layers off:\n{msg}"
+
+
+@pytest.mark.parametrize("name", ["mobilenetv1", "mobilenetv2", "mobilenetv3_small", "mobilenetv3_large"])
+def test_embeddings_vs_reference_golden_f32(name, golden_dir, golden_x):
+    g = np.load(os.path.join(golden_dir, f"emb_{name}.npz"))
+    with torch.no_grad():
+        y = product(name)(golden_x.to(DEV), precision="f32").cpu().numpy()
+    c = cos_rows(y, g["emb"])
+    assert c.min() >= COS_BAR, c
+    assert np.abs(np.linalg.norm(y, axis=1) / np.linalg.norm(g["emb"], axis=1) - 1).max() < 1e-2
+
+
+@pytest.mark.parametrize("name", ["mobilenetv3_small", "mobilenetv3_large"])
+def test_embeddings_vs_reference_golden_bf16(name, golden_dir, golden_x):
+    """BASELINE configs 1-2 name the bf16 path: single-pass bf16 operands, fp32 accumulate."""
+    g = np.load(os.path.join(golden_dir, f"emb_{name}.npz"))
+    with torch.no_grad():
+        y = product(name)(golden_x.to(DEV), precision="bf16").cpu().numpy()
+    c = cos_rows(y, g["emb"])
+    assert c.min() >= COS_BAR, c
+
+
+@pytest.mark.parametrize("name", ["mobilenetv1", "mobilenetv2", "mobilenetv3_small", "mobilenetv3_large"])
+def test_bn_calibrated_weights_f32(name, golden_dir, golden_x):
+    """'Trained-like' BatchNorm statistics captured from the reference (harder: real cancellation)."""
+    g = np.load(os.path.join(golden_dir, f"bncal_{name}.npz"))
+    sd = ob.seeded(name, 0).state_dict()
+    for i, k in enumerate(g["keys"]):
+        sd[str(k)] = torch.from_numpy(g[f"s{i}"])
+    with torch.no_grad():
+        y = product(name, sd)(golden_x.to(DEV), precision="f32").cpu().numpy()
+    c = cos_rows(y, g["emb"])
+    assert c.min() >= COS_BAR, c
+    assert np.abs(y - g["emb"]).max() <= 2e-3 * np.abs(g["emb"]).max()
+
+
+def test_batch_sizes_and_determinism(golden_x):
+    m = product("mobilenetv3_small")
+    x = golden_x.to(DEV)
+    with torch.no_grad():
+        full = m(x, precision="f32")
+        one = torch.cat([m(x[i:i + 1], precision="f32") for i in range(len(x))])
+        again = m(x, precision="f32")
+        big = m(x.repeat(33, 1, 1, 1), precision="f32")      # 264 images: crosses tile boundaries
+        empty = m(x[:0], precision="f32")
+    assert torch.equal(full, again)
+    assert torch.equal(full, one)
+    assert torch.equal(big[:8], full) and torch.equal(big[-8:], full)
+    assert empty.shape == (0, 512)
+
+
+def test_pair_scoring_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pairs.npz"))
+    a, b = torch.from_numpy(g["a"]).to(DEV), torch.from_numpy(g["b"]).to(DEV)
+    s0, d0 = fr.cosine_pairs(a, b, eps=0.0, threshold=0.35)
+    s1, d1 = fr.cosine_pairs(a, b, eps=1e-5, threshold=0.35)
+    assert np.abs(s0.cpu().numpy() - g["sim_np"]).max() <= 1e-3
+    assert np.abs(s1.cpu().numpy() - g["sim_lfw"]).max() <= 1e-3
+    # decisions: identical wherever the reference similarity is not within fp32 rounding of 0.35
+    far = np.abs(g["sim_lfw"] - 0.35) > 2e-6
+    assert np.array_equal(d1.cpu().numpy()[far].astype(int), g["dec_lfw"][far])
+    far0 = np.abs(g["sim_np"].astype(np.float64) - 0.35) > 2e-6
+    assert np.array_equal(d0.cpu().numpy()[far0], g["dec_np"][far0])
+    assert np.float32 == type(fr.compute_similarity(g["a"][0], g["b"][0]))
+    assert fr.cosine_pairs(a[:0], b[:0])[0].numel() == 0
+
+
+def _lfw_fixture(tmp_path, n_ids=40, per_id=3, n_pairs=120, seed=3):
+    faces = osc.synthetic_faces(n_ids, per_id, seed=1234)
+    rng = np.random.default_rng(seed)
+    images, lines = {}, ["header line is dropped\n"]
+    root = str(tmp_path)
+    for i in range(n_ids):
+        for j in range(per_id):
+            images[os.path.join(root, f"id{i}", f"id{i}_{j + 1:04d}.jpg")] = faces[i, j]
+    for p in range(n_pairs):
+        i = int(rng.integers(n_ids))
+        if p % 2 == 0:
+            a, b = rng.choice(per_id, 2, replace=False) + 1
+            lines.append(f"id{i} {a} {b}\n")
+        else:
+            k = int((i + 1 + rng.integers(n_ids - 1)) % n_ids)
+            lines.append(f"id{i} {int(rng.integers(per_id)) + 1} id{k} {int(rng.integers(per_id)) + 1}\n")
+    lines.append("id0 1 id1 99\n")          # missing image -> pair skipped (evaluate.py:547-549)
+    lines.append("malformed\n")
+    with open(os.path.join(root, "lfw_ann.txt"), "w") as f:
+        f.writelines(lines)
+    return root, images, lines[1:]
+
+
+@pytest.mark.parametrize("calibrated", [False, True])
+def test_lfw_pair_verification_config1(tmp_path, golden_dir, calibrated):
+    """BASELINE config 1 (reduced pair count so the CPU oracle's batch-1 loop stays short):
+    mobilenetv3_small, LFW-layout annotation, eval() triple vs the oracle's restated pair loop."""
+    root, images, pair_lines = _lfw_fixture(tmp_path)
+    onet = ob.seeded("mobilenetv3_small", 0)
+    if calibrated:
+        g = np.load(os.path.join(golden_dir, "bncal_mobilenetv3_small.npz"))
+        sd = onet.state_dict()
+        for i, k in enumerate(g["keys"]):
+            sd[str(k)] = torch.from_numpy(g[f"s{i}"])
+        onet.load_state_dict(sd)
+    model = product("mobilenetv3_small", onet.state_dict())
+    model.precision = "f32"
+
+    def loader(path):
+        if path not in images:
+            raise FileNotFoundError(path)
+        return images[path]
+
+    mean, preds, metrics = fr.evaluate.eval(model, device=DEV, val_root=root, compute_full_metrics=True,
+                                            image_loader=loader)
+    omean, opreds, _ = osc.eval_pairs(onet, images, pair_lines, root)
+    assert preds.shape == opreds.shape == (120, 4)
+    assert list(preds[:, 0]) == list(opreds[:, 0]) and list(preds[:, 3]) == list(opreds[:, 3])
+    s, o = preds[:, 2].astype(float), opreds[:, 2].astype(float)
+    assert np.abs(s - o).max() <= 1e-3
+    far = np.abs(o - 0.35) > 1e-3
+    assert np.array_equal(osc.decide(s)[far], osc.decide(o)[far])
+    assert abs(mean - omean) <= 1e-3 and abs(metrics["mean_similarity"] - omean) <= 1e-3
+    if calibrated:
+        assert osc.decide(o).sum() > 0                    # non-trivial decisions
+    else:
+        assert np.all(osc.decide(s) == 0)                 # raw init + 1e-5 eps: all "different" 
+
+
+def test_synthetic_rows_bit_exact():
+    G, npl = 5000, 16
+    got = fr.search.synth_rows(7, 1000, 700, DEV, plant_seed=11, n_plant=npl, n_gallery_total=G)
+    want = osr.gallery_rows(7, 11, 1000, 700, G, npl)
+    assert np.array_equal(got.view(torch.int16).cpu().numpy().view(np.uint16), want)
+    q = fr.search.synth_rows(11, 0, 33, DEV)
+    assert np.array_equal(q.view(torch.int16).cpu().numpy().view(np.uint16), osr.query_rows(11, 0, 33))
+
+
+@pytest.mark.parametrize("Q,G", [(64, 4096), (130, 1000), (1, 129), (257, 20011)])
+def test_topk_search_parity(Q, G):
+    npl = min(8, Q)
+    g = fr.search.synth_rows(7, 0, G, DEV, plant_seed=11, n_plant=npl, n_gallery_total=G)
+    q = fr.search.synth_rows(11, 0, Q, DEV)
+    s, i = fr.search.Matcher(g, k=5).search(q)
+    gf = osr.bf16_bits_to_f32(g.view(torch.int16).cpu().numpy().view(np.uint16))
+    qf = osr.bf16_bits_to_f32(q.view(torch.int16).cpu().numpy().view(np.uint16))
+    os_, oi, gap = osr.topk_cosine(qf, gf, 5)
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    assert np.abs(s - os_).max() <= 1e-3
+    # exact index equality rank by rank wherever neighbouring scores are separated by > 1e-5
+    full = osr.topk_cosine(qf, gf, 6)[0] if G > 5 else None
+    for r in range(Q):
+        seps = np.abs(np.diff(np.concatenate([os_[r], [os_[r, -1] - gap[r]]])))
+        ok = seps > 1e-5
+        clear = np.concatenate([[True], ok[:-1]]) & ok
+        assert np.array_equal(i[r][clear], oi[r][clear]), (r, i[r], oi[r])
+    for t in range(npl):
+        assert i[t, 0] == osr.plant_row(t, G, npl)
+    assert np.all(np.diff(s, axis=1) <= 0)
+
+
+def test_sharded_search_equals_single(golden_x):
+    """Fake-shard mode: P shards on one device, merged on the GPU, must equal
+    the single-shard search exactly (deterministic tie rule)."""
+    G, Q = 30000, 96
+    g = fr.search.synth_rows(7, 0, G, DEV, plant_seed=11, n_plant=8, n_gallery_total=G)
+    q = fr.search.synth_rows(11, 0, Q, DEV)
+    s1, i1 = fr.search.Matcher(g, k=5).search(q)
+    for P in (2, 3, 8):
+        parts = []
+        for r in range(P):
+            lo, hi = fr.search.shard_range(G, r, P)
+            local = fr.search.synth_rows(7, lo, hi - lo, DEV, plant_seed=11, n_plant=8, n_gallery_total=G)
+            parts.append(fr.search.Matcher(local, idx_offset=lo, k=5).search(q))
+        ms, mi = fr.search.merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), 5)
+        assert torch.equal(mi, i1) and torch.equal(ms, s1)
+
+
+def test_embedding_to_gallery_roundtrip(golden_x):
+    """Embeddings -> normalised bf16 gallery -> each image retrieves itself at rank 1."""
+    m = product("mobilenetv3_small")
+    with torch.no_grad():
+        e = m(golden_x.to(DEV), precision="f32")
+    gal = fr.search.normalize_rows_bf16(e)
+    s, i = fr.search.Matcher(gal, k=5).search(gal)
+    assert i[:, 0].cpu().tolist() == list(range(8))
+    y, nrm = fr.search.l2norm(e)
+    assert torch.allclose(y.norm(dim=1), torch.ones(8, device=DEV), atol=1e-5)
+    assert torch.allclose(nrm, e.norm(dim=1), rtol=1e-5)

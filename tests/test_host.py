@@ -1,0 +1,136 @@
+"""CPU: host logic of the product package and the C-ABI library (no compute calls: no GPU here)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import face_recognition_amd as fr
+from face_recognition_amd import _lib
+from oracle import backbones as ob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "fr_hip.h")).read()
+    declared = set(re.findall(r"\b(fr_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"fr_layer_desc"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = _lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert ctypes.sizeof(_lib.LayerDesc) == 10 * 4 + 6 * 8 + 8 + 3 * 8   # matches the C struct layout
+
+
+@pytest.mark.parametrize("name", ob.MODEL_NAMES)
+def test_product_random_init_equals_reference(name, golden_dir):
+    sha = json.load(open(os.path.join(golden_dir, "state_sha256.json")))
+    torch.manual_seed(0)
+    m = fr.get_network(name)
+    assert ob.state_dict_sha256(m.state_dict()) == sha[name]
+
+
+@pytest.mark.parametrize("name", ["mobilenetv1", "mobilenetv2", "mobilenetv3_small", "mobilenetv3_large", "sphere20"])
+def test_lowering_covers_every_unit(name):
+    m = fr.get_network(name).eval()
+    names = m.layer_names()
+    units = ob.unit_names(ob.build(name))
+    assert names[:len(units)] == units or set(units) <= set(names)
+    assert len(set(names)) == len(names)
+
+
+def test_checkpoint_roundtrip_and_error_conventions(tmp_path):
+    torch.manual_seed(1)
+    src = fr.get_network("mobilenetv3_small")
+    bare = tmp_path / "w.pth"
+    torch.save(src.state_dict(), bare)
+    m = fr.load_model("mobilenetv3_small", str(bare), torch.device("cpu"))
+    assert not m.training and ob.state_dict_sha256(m.state_dict()) == ob.state_dict_sha256(src.state_dict())
+    import argparse
+    ck = tmp_path / "w.ckpt"
+    torch.save({"epoch": 3, "model": src.state_dict(), "args": argparse.Namespace(lr=0.1)}, ck)
+    m2 = fr.load_model("mobilenetv3_small", str(ck), torch.device("cpu"))
+    assert ob.state_dict_sha256(m2.state_dict()) == ob.state_dict_sha256(src.state_dict())
+    # the oracle loads the same checkpoint (state_dict-identical)
+    ob.build("mobilenetv3_small").load_state_dict(torch.load(bare))
+    with pytest.raises(ValueError):
+        fr.get_network("resnet50")
+    with pytest.raises(RuntimeError):
+        fr.load_model("mobilenetv3_small", str(tmp_path / "missing.pth"), torch.device("cpu"))
+    with pytest.raises(RuntimeError):
+        fr.load_model("mobilenetv2", str(bare), torch.device("cpu"))          # wrong architecture: strict load fails
+    with pytest.raises(FileNotFoundError):
+        fr.extract_features(m, torch.device("cpu"), str(tmp_path / "nope.jpg"))
+
+
+def test_no_cpu_fallback():
+    m = fr.get_network("mobilenetv1").eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 112, 112))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fr.cosine_pairs(torch.zeros(2, 512), torch.zeros(2, 512))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fr.search.Matcher(torch.zeros(4, 512, dtype=torch.bfloat16))
+    src = "".join(open(os.path.join(ROOT, "face-recognition_amd", f)).read()
+                  for f in os.listdir(os.path.join(ROOT, "face-recognition_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_eval_missing_annotation_returns_empty_triple(tmp_path):
+    m = fr.get_network("mobilenetv1")
+    mean, preds, metrics = fr.evaluate.eval(m, device=torch.device("cpu"), val_root=str(tmp_path))
+    assert mean == 0.0 and preds.size == 0 and metrics == {}
+
+
+def test_transform_matches_oracle():
+    from oracle import scoring as osc
+    from PIL import Image
+    a = np.random.default_rng(0).integers(0, 256, (112, 112, 3), dtype=np.uint8)
+    assert torch.equal(fr.get_transform()(Image.fromarray(a)), osc.to_model_input(a))
+
+
+def test_shard_ranges_partition_the_gallery():
+    for G, P in ((100, 8), (10_000_001, 4), (7, 8)):
+        r = [fr.search.shard_range(G, i, P) for i in range(P)]
+        assert r[0][0] == 0 and r[-1][1] == G and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+
+
+def _gloo_worker(rank, world, port, q):
+    try:
+        _gloo_body(rank, world, port, q)
+    except Exception as e:                      # surface the failure instead of a queue timeout
+        q.put((rank, False, repr(e)))
+
+
+def _gloo_body(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import search as osr
+    G, Q, k = 1500, 16, 5
+    g = osr.bf16_bits_to_f32(osr.gallery_rows(7, 11, 0, G, G, 4))
+    qs = osr.bf16_bits_to_f32(osr.query_rows(11, 0, Q))
+    lo, hi = fr.search.shard_range(G, rank, world)
+    s, i, _ = osr.topk_cosine(qs, g[lo:hi], k, idx_offset=lo)           # stand-in for the local HIP search
+    gs, gi = fr.search.all_gather_topk(torch.from_numpy(s).float(), torch.from_numpy(i))
+    ms, mi = osr.merge_topk(gs.numpy(), gi.numpy(), k)
+    fs, fi, _ = osr.topk_cosine(qs, g, k)
+    q.put((rank, bool(np.array_equal(mi, fi)), tuple(gs.shape)))
+    dist.destroy_process_group()
+
+
+def test_sharded_exchange_world_size_2_gloo():
+    """The N>1 path on CPU: shard ranges + all_gather of per-shard top-k + deterministic merge."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(60) for p in procs]
+    assert all(ok for _, ok, _ in res) and all(shape == (2, 16, 5) for _, _, shape in res)
