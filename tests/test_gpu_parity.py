@@ -34,11 +34,21 @@ def product(name, state_dict=None):
 def layer_report(model, oracle, x, precision):
     """Per-plan-layer cosine / relative max error against oracle forward hooks."""
     names = model.layer_names()
-    onames = [n for n in names if n in dict(oracle.named_modules())]
-    _, taps = ob.forward_with_taps(oracle, x, onames)
+    mods = dict(oracle.named_modules())
+    # a unit that closes a residual block is compared at the block's output (the oracle hook on the
+    # unit itself fires before the skip connection is added)
+    where = {}
+    for n in names:
+        if n not in mods:
+            continue
+        parent = n.rsplit(".", 2)[0]
+        closes = getattr(mods.get(parent), "residual", False) and n == [k for k in names if k.startswith(parent + ".")][-1]
+        where[n] = parent if closes else n
+    _, taps_raw = ob.forward_with_taps(oracle, x, sorted(set(where.values())))
+    taps = {n: taps_raw[w] for n, w in where.items()}
     rows = []
     for i, n in enumerate(names):
-        if n not in taps or isinstance(dict(oracle.named_modules())[n], ob.SqueezeExcite):
+        if n not in taps or isinstance(mods[n], ob.SqueezeExcite):
             continue
         _, t = model.forward_tap(x.to(DEV), i, precision)
         ref = taps[n].numpy().reshape(len(x), -1)
@@ -204,11 +214,12 @@ def test_topk_search_parity(Q, G):
     os_, oi, gap = osr.topk_cosine(qf, gf, 5)
     s, i = s.cpu().numpy(), i.cpu().numpy()
     assert np.abs(s - os_).max() <= 1e-3
-    # exact index equality rank by rank wherever neighbouring scores are separated by > 1e-5
+    # exact index equality rank by rank wherever neighbouring scores are separated by > 5e-5
+    # (20x tighter than the 1e-3 bar; fp32 accumulation of 512 products is good to ~1e-5)
     full = osr.topk_cosine(qf, gf, 6)[0] if G > 5 else None
     for r in range(Q):
         seps = np.abs(np.diff(np.concatenate([os_[r], [os_[r, -1] - gap[r]]])))
-        ok = seps > 1e-5
+        ok = seps > 5e-5
         clear = np.concatenate([[True], ok[:-1]]) & ok
         assert np.array_equal(i[r][clear], oi[r][clear]), (r, i[r], oi[r])
     for t in range(npl):
