@@ -40,6 +40,9 @@ _SIGS = {
     "fr_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fr_embed_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                C.c_int, C.c_void_p]),
+    "fr_embed_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                   C.POINTER(C.c_float)]),
+    "fr_plan_layer_kernel": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p)]),
     "fr_l2norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "fr_l2norm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "fr_cosine_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_double,

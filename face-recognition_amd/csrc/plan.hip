@@ -334,10 +334,11 @@ extern "C" int fr_plan_layer_dims(const fr_plan* plan, int layer, int* c, int* h
 
 extern "C" int fr_plan_num_launches(const fr_plan* plan) { return plan ? plan->launches : FR_ERR_ARG; }
 
-extern "C" int fr_embed_tap(const fr_plan* plan, const float* x, int batch, float* out,
-                            void* workspace, size_t workspace_bytes, void* stream,
-                            int tap_layer, float* tap_out) {
+static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out,
+                      void* workspace, size_t workspace_bytes, void* stream,
+                      int tap_layer, float* tap_out, hipEvent_t* events) {
     if (!plan || !x || !out || batch <= 0) FR_FAIL(FR_ERR_ARG, "fr_embed: bad arguments");
+    (void)events;
     size_t need = 0;
     fr_plan_workspace_bytes(plan, batch, &need);
     if (!workspace || workspace_bytes < need) FR_FAIL(FR_ERR_WORKSPACE, "fr_embed: workspace too small");
@@ -358,6 +359,7 @@ extern "C" int fr_embed_tap(const fr_plan* plan, const float* x, int batch, floa
         in_nhwc = base[plan->input_slot];
     }
     const int nl = (int)plan->layers.size();
+    if (events) FR_HIP_CHECK(hipEventRecord(events[0], st));
     for (int i = 0; i < nl; ++i) {
         const Layer& L = plan->layers[i];
         const bool last = (i == nl - 1);
@@ -438,7 +440,39 @@ extern "C" int fr_embed_tap(const fr_plan* plan, const float* x, int batch, floa
             if (L.kind == K_GDW || L.kind == K_SE) FR_HIP_CHECK(hipMemcpyAsync(out, y, (size_t)N * L.C * 4, hipMemcpyDeviceToDevice, st));
             else { rc = launch_nhwc_to_nchw(y, L.out_f32, out, N, L.C, L.H, L.W, st); if (rc) return rc; }
         }
+        if (events) FR_HIP_CHECK(hipEventRecord(events[i + 1], st));
     }
+    return FR_OK;
+}
+
+extern "C" int fr_embed_tap(const fr_plan* plan, const float* x, int batch, float* out,
+                            void* workspace, size_t workspace_bytes, void* stream,
+                            int tap_layer, float* tap_out) {
+    return embed_impl(plan, x, batch, out, workspace, workspace_bytes, stream, tap_layer, tap_out, nullptr);
+}
+
+extern "C" int fr_embed_profile(const fr_plan* plan, const float* x, int batch, float* out,
+                                void* workspace, size_t workspace_bytes, void* stream, float* layer_ms) {
+    if (!plan || !layer_ms) FR_FAIL(FR_ERR_ARG, "fr_embed_profile: bad arguments");
+    const int nl = (int)plan->layers.size();
+    std::vector<hipEvent_t> ev(nl + 1);
+    for (auto& e : ev) FR_HIP_CHECK(hipEventCreate(&e));
+    int rc = embed_impl(plan, x, batch, out, workspace, workspace_bytes, stream, -1, nullptr, ev.data());
+    if (rc == FR_OK) {
+        hipError_t he = hipEventSynchronize(ev[nl]);
+        if (he != hipSuccess) { fr_set_error(std::string("hipEventSynchronize: ") + hipGetErrorString(he)); rc = FR_ERR_HIP; }
+        for (int i = 0; i < nl && rc == FR_OK; ++i)
+            if (hipEventElapsedTime(&layer_ms[i], ev[i], ev[i + 1]) != hipSuccess) { fr_set_error("hipEventElapsedTime failed"); rc = FR_ERR_HIP; }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char** name) {
+    if (!plan || layer < 0 || layer >= (int)plan->layers.size() || !name) FR_FAIL(FR_ERR_ARG, "fr_plan_layer_kernel: bad layer");
+    static const char* names[] = {"stem_kernel", "pw_gemm_kernel", "dw_kernel", "reduce_kernel", "se(reduce+2xpw_gemm)",
+                                  "pw_gemm_kernel", "conv3x3_kernel"};
+    *name = names[plan->layers[layer].kind];
     return FR_OK;
 }
 

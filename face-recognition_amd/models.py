@@ -200,6 +200,8 @@ class _Plan:
         self.lib = _lib.lib()
         self.device = torch.device("cuda", device_index)
         self.names = list(g.names)
+        self.srcs = [int(d.src) for d in g.descs]
+        self.ops = [int(d.op) for d in g.descs]
         self.n_layers = len(g.descs)
         arr = (_lib.LayerDesc * self.n_layers)(*g.descs)
         handle = C.c_void_p()
@@ -232,6 +234,23 @@ class _Plan:
             self._ws = None
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def profile(self, x: torch.Tensor):
+        """Per-layer device milliseconds of one fr_embed call: [(name, kernel, ms, src_index)]."""
+        x = x.to(torch.float32).contiguous()
+        n = x.shape[0]
+        out = torch.empty((n, self.dims[-1][0]), dtype=torch.float32, device=x.device)
+        ws = self.workspace(n)
+        ms = (C.c_float * self.n_layers)()
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.fr_embed_profile(self.handle, x.data_ptr(), n, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 torch.cuda.current_stream(x.device).cuda_stream, ms), "fr_embed_profile")
+        rows = []
+        nm = C.c_char_p()
+        for i in range(self.n_layers):
+            _lib.check(self.lib.fr_plan_layer_kernel(self.handle, i, C.byref(nm)), "fr_plan_layer_kernel")
+            rows.append((self.names[i], nm.value.decode(), float(ms[i]), self.srcs[i]))
+        return rows
 
     def run(self, x: torch.Tensor, tap: int = -1):
         x = x.to(torch.float32).contiguous()

@@ -102,6 +102,13 @@ int fr_embed_tap(const fr_plan* plan, const float* x, int batch, float* out,
                  void* workspace, size_t workspace_bytes, void* stream,
                  int tap_layer, float* tap_out);
 
+/* Diagnostics (no reference counterpart): run fr_embed with a hipEvent pair around every layer on
+ * `stream`, synchronise, and return the per-layer device time in milliseconds (layer_ms[n_layers],
+ * HOST pointer).  fr_plan_layer_kernel names the kernel family that executes a layer. */
+int fr_embed_profile(const fr_plan* plan, const float* x, int batch, float* out,
+                     void* workspace, size_t workspace_bytes, void* stream, float* layer_ms);
+int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char** name);
+
 /* L2-normalise rows: y = x / max(||x||, tiny); norms[n] optional (may be NULL).  The reference
  * normalises inside its similarity formulas only; this is the gallery/query preparation step. */
 int fr_l2norm(const float* x, float* y, float* norms, int n, int d, void* stream);
