@@ -38,6 +38,17 @@ struct StemArgs {
 };
 int launch_stem(bool out_f32, const StemArgs& a, hipStream_t st);
 
+// ---- dense KxK conv (K = 3) / large-K linear (K = 1) as MFMA implicit GEMM
+struct ConvArgs {
+    const void* x;        // [N,H,W,Cin] activations
+    const bf16* w;        // packed [cout tile][ks][NS][BN][32], ks = tap * (Cin/32) + chunk
+    EpiArgs e;
+    long M;               // N*Ho*Wo
+    int H, W, Ho, Wo, Cin, ksize, stride, pad;
+};
+int launch_conv(bool in_f32, bool out_f32, const ConvArgs& a, hipStream_t st);
+int conv_block_couts(int cout);   // couts per block tile (64 or 128): the packing granularity
+
 // ---- weighted spatial reduction: out[n][c] = sum_p x[n][p][c] * w[p][c] (+ b[c]); w NULL -> 1/P
 struct ReduceArgs {
     const void* x;        // [N,P,C]

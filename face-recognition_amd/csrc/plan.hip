@@ -35,6 +35,7 @@ struct Layer {
     float* slope = nullptr;
     int K = 0, KS = 0, NT = 0, chunk_ks = 0;       // GEMM geometry
     int K2 = 0, KS2 = 0, NT2 = 0, chunk_ks2 = 0;   // SE fc2 geometry
+    bool via_conv = false;                // Linear routed through the conv implicit-GEMM kernel
 };
 
 }  // namespace
@@ -103,6 +104,28 @@ void pack_gemm_weights(const std::vector<double>& W, int cout, int K, int ns, st
             }
     *KS_out = KS;
     *NT_out = NT;
+}
+
+// Pack W(cout, tap, c) into the LDS image of conv_gemm_kernel: [cout tile][ks][NS][BN rows][32].
+template <typename F>
+void pack_conv_weights(F&& wfn, int cout, int cin, int taps, int ns, std::vector<uint16_t>& out) {
+    const int bn = conv_block_couts(cout), ntiles = cdiv(cout, bn), chunks = cin / 32, KS = taps * chunks;
+    out.assign((size_t)ntiles * KS * ns * bn * 32, 0);
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int ks = 0; ks < KS; ++ks) {
+            const int tap = ks / chunks, c0 = (ks % chunks) * 32;
+            for (int r = 0; r < bn; ++r) {
+                const int co = nt * bn + (r / 32) * 32 + mfma_row_to_cout(r % 32);
+                if (co >= cout) continue;
+                for (int kk = 0; kk < 32; ++kk) {
+                    const double w = wfn(co, tap, c0 + kk);
+                    const uint16_t hi = host_f2bf((float)w);
+                    const size_t base = ((((size_t)nt * KS + ks) * ns) * bn + r) * 32 + kk;
+                    out[base] = hi;
+                    if (ns == 2) out[base + (size_t)bn * 32] = host_f2bf((float)(w - (double)host_bf2f(hi)));
+                }
+            }
+        }
 }
 
 std::vector<float> padded(const std::vector<double>& v, int n) {
@@ -186,7 +209,14 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
                 L.kind = K_DW;
             }
         } else if (d.groups == 1 && d.kernel == 3) {
-            FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "dense 3x3 conv not built yet");
+            if (d.pad != 1 || (d.stride != 1 && d.stride != 2) || d.cin % 32)
+                FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "dense 3x3 conv needs pad 1, stride 1|2, cin % 32 == 0");
+            L.kind = K_CONV3;
+            std::vector<uint16_t> packed;
+            const int cin = d.cin;
+            pack_conv_weights([&](int co, int tap, int c) { return (double)d.weight[((size_t)co * cin + c) * 9 + tap] * scale[co]; },
+                              d.cout, d.cin, 9, L.in_f32 ? 2 : 1, packed);
+            int rc = upload(pl, packed, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
         } else {
             FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "conv shape with no kernel");
         }
@@ -237,10 +267,16 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
                 for (int p = 0; p < HW; ++p)
                     W[(size_t)o * K + (size_t)p * s.C + c] = (double)d.weight[(size_t)o * K + (size_t)c * HW + p] * scale[o];
         std::vector<uint16_t> packed;
-        pack_gemm_weights(W, d.cout, K, L.in_f32 ? 2 : 1, packed, &L.KS, &L.NT);
-        int rc = upload(pl, packed, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
-        int ntb; pw_pick_tiling(L.in_f32, L.NT, L.KS, &ntb, &L.chunk_ks);
-        rc = upload(pl, padded(shift, cdiv(d.cout, 32) * 32), &L.bias); if (rc) return rc;
+        int rc;
+        if (K >= 4096 && K % 32 == 0) {           // SphereFace fc: K-streaming implicit-GEMM kernel
+            L.via_conv = true;
+            pack_conv_weights([&](int co, int, int c) { return W[(size_t)co * K + c]; }, d.cout, K, 1, L.in_f32 ? 2 : 1, packed);
+        } else {
+            pack_gemm_weights(W, d.cout, K, L.in_f32 ? 2 : 1, packed, &L.KS, &L.NT);
+            int ntb; pw_pick_tiling(L.in_f32, L.NT, L.KS, &ntb, &L.chunk_ks);
+        }
+        rc = upload(pl, packed, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
+        rc = upload(pl, padded(shift, cdiv(d.cout, 128) * 128), &L.bias); if (rc) return rc;
         if (d.act == FR_ACT_PRELU) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "PReLU after Linear");
         if (d.residual >= 0) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "residual after Linear");
     } else {
@@ -383,7 +419,24 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
                 rc = launch_stem(L.out_f32, a, st);
                 break;
             }
+            case K_CONV3: {
+                ConvArgs a{};
+                a.x = xin; a.w = L.w_packed;
+                a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act};
+                a.M = (long)N * L.H * L.W; a.H = L.inH; a.W = L.inW; a.Ho = L.H; a.Wo = L.W;
+                a.Cin = L.cin; a.ksize = 3; a.stride = L.stride; a.pad = L.pad;
+                rc = launch_conv(L.in_f32, L.out_f32, a, st);
+                break;
+            }
             case K_PW: case K_LINEAR: {
+                if (L.via_conv) {
+                    ConvArgs a{};
+                    a.x = xin; a.w = L.w_packed;
+                    a.e = EpiArgs{L.bias, nullptr, nullptr, y, L.cout, L.act};
+                    a.M = N; a.H = a.W = a.Ho = a.Wo = 1; a.Cin = L.K; a.ksize = 1; a.stride = 1; a.pad = 0;
+                    rc = launch_conv(L.in_f32, true, a, st);
+                    break;
+                }
                 PwArgs a{};
                 a.x = xin; a.w = L.w_packed; a.se = se;
                 a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act};

@@ -241,6 +241,8 @@ class MobileNetV3(nn.Module):
 class _SphereResidual(nn.Module):
     """models/sphereface.py:10-48: two bias-free 3x3 conv + PReLU, no norm; x + block(x)."""
 
+    residual = True
+
     def __init__(self, c: int) -> None:
         super().__init__()
         self.block = nn.Sequential(_cna(c, c, 3, norm=False, bias=False),

@@ -59,7 +59,7 @@ def layer_report(model, oracle, x, precision):
 
 
 @pytest.mark.parametrize("precision,bar,relbar", [("f32", 0.999999, 1e-3), ("bf16", 0.9995, 0.1)])
-@pytest.mark.parametrize("name", ["mobilenetv3_large", "mobilenetv3_small", "mobilenetv2", "mobilenetv1"])
+@pytest.mark.parametrize("name", ["mobilenetv3_large", "mobilenetv3_small", "mobilenetv2", "mobilenetv1", "sphere20"])
 def test_every_layer_against_oracle_hooks(name, precision, bar, relbar, golden_x):
     """Each fused unit (conv+BN+act, project+residual, SE-scaled project, GDC) vs the oracle's hook at
     the same point.  f32 mode must track to ~1e-6; bf16 mode within bf16 rounding accumulation."""
@@ -78,6 +78,19 @@ def test_embeddings_vs_reference_golden_f32(name, golden_dir, golden_x):
     c = cos_rows(y, g["emb"])
     assert c.min() >= COS_BAR, c
     assert np.abs(np.linalg.norm(y, axis=1) / np.linalg.norm(g["emb"], axis=1) - 1).max() < 1e-2
+
+
+@pytest.mark.parametrize("name", ["sphere20", "sphere36", "sphere64"])
+def test_sphereface_embeddings_vs_reference_golden(name, golden_dir, golden_x):
+    """BASELINE config 3 family: dense 3x3 MFMA path + PReLU + residual + NCHW-flatten fc."""
+    g = np.load(os.path.join(golden_dir, f"emb_{name}.npz"))
+    m = product(name)
+    with torch.no_grad():
+        for prec in ("bf16", "f32"):
+            y = m(golden_x.to(DEV), precision=prec).cpu().numpy()
+            c = cos_rows(y, g["emb"])
+            assert c.min() >= COS_BAR, (prec, c)
+            assert np.abs(np.linalg.norm(y, axis=1) / np.linalg.norm(g["emb"], axis=1) - 1).max() < 1e-2
 
 
 @pytest.mark.parametrize("name", ["mobilenetv3_small", "mobilenetv3_large"])
