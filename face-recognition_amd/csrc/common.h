@@ -90,6 +90,32 @@ FR_DEV float apply_act(float v, int act, float slope) {
     }
 }
 
+// Activation of 8 channels with ONE uniform branch per vector (apply_act per element makes the
+// compiler emit a switch per element).
+FR_DEV void act8(Vec8f& v, int act, const float* slope8) {
+    if (act == FR_ACT_PRELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v.v[j] = v.v[j] >= 0.f ? v.v[j] : v.v[j] * slope8[j];
+    } else if (act == FR_ACT_HSWISH) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v.v[j] = v.v[j] * fminf(fmaxf(v.v[j] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    } else if (act == FR_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v.v[j] = fmaxf(v.v[j], 0.f);
+    } else if (act == FR_ACT_HSIGMOID) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v.v[j] = fminf(fmaxf(v.v[j] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    }
+}
+
+// n / d for n*d < 2^32 with a per-block precomputed multiplier (loops index LDS tiles with it).
+struct FastDiv {
+    unsigned long long mul; unsigned d;
+    FR_DEV explicit FastDiv(unsigned dd) : mul((1ull << 32) / dd + 1ull), d(dd) {}
+    FR_DEV unsigned div(unsigned n) const { return (unsigned)(((unsigned long long)n * mul) >> 32); }
+    FR_DEV void divmod(unsigned n, unsigned& q, unsigned& r) const { q = div(n); r = n - q * d; }
+};
+
 // Split 8 fp32 values into bf16 hi and lo fragments: x ~= hi + lo with ~16 mantissa bits.
 FR_DEV void split8(const Vec8f& x, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -144,8 +170,7 @@ FR_DEV void epilogue_store(const f32x16& acc, const EpiArgs& e, long m, int c0, 
                 v.v[4 + i] = v.v[4 + i] >= 0.f ? v.v[4 + i] : v.v[4 + i] * s1[i];
             }
         } else if (e.act != FR_ACT_NONE) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v.v[i] = apply_act(v.v[i], e.act, 0.f);
+            act8(v, e.act, nullptr);
         }
         long off = m * (long)e.cout + c;
         if (e.residual) {

@@ -6,17 +6,11 @@
 // coalesced 16-byte loads (zero-filled outside the image), then every thread produces strips of
 // 4 horizontally adjacent outputs for one 8-channel vector, re-using each LDS read for up to K/S
 // outputs.  fp32 accumulate, fp32 weights (tap-major [K*K][C], BN folded in), one rounding at the store.
-#include "kernels.h"
-
-template <typename T>
-struct V8 { T v[8]; };   // 8 channels as stored (16 B for bf16, 32 B for fp32)
+#include "dw_core.h"
 
 template <typename T, int K, int S>
 __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
-    constexpr int SW = 4;
-    constexpr int IWS = (SW - 1) * S + K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
     int b = blockIdx.x;
     const int cc = b % a.cchunks; b /= a.cchunks;
     const int tx = b % a.tiles_x; b /= a.tiles_x;
@@ -35,9 +29,11 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
 
     const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;
     const int nin = IH * IW * ncv;
+    const FastDiv d_ncv(ncv), d_iw(IW);
     for (int i = threadIdx.x; i < nin; i += 256) {
-        const int cv = i % ncv, pix = i / ncv;
-        const int iy = pix / IW, ix = pix - iy * IW;
+        unsigned cv, pix, iy, ix;
+        d_ncv.divmod(i, pix, cv);
+        d_iw.divmod(pix, iy, ix);
         const int gy = gy0 + iy, gx = gx0 + ix;
         V8<T> v;
         if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
@@ -48,83 +44,9 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
         }
         tile[i] = v;
     }
-    for (int i = threadIdx.x; i < K * K * ncv * 8; i += 256) {
-        const int j = i & 3; int r = i >> 2;
-        const int cv = r % ncv; r /= ncv;
-        const int half = r & 1, tap = r >> 1;
-        wl[i] = a.w[(long)tap * a.C + (cv0 + cv) * 8 + half * 4 + j];
-    }
-    for (int i = threadIdx.x; i < ncv * 8; i += 256) {
-        const int j = i & 3; int r = i >> 2;
-        const int cv = r % ncv; const int half = r / ncv;
-        const int c = (cv0 + cv) * 8 + half * 4 + j;
-        bl[i] = a.bias[c];
-        bl[ncv * 8 + i] = a.slope ? a.slope[c] : 0.f;
-    }
+    dw_stage_params<T, K, S>(a, wl, bl, cv0, ncv);
     __syncthreads();
-
-    const int nstrips = a.TW / SW;
-    const int nitems = a.TH * nstrips * ncv;
-    T* Y = reinterpret_cast<T*>(a.y);
-    for (int it = threadIdx.x; it < nitems; it += 256) {
-        const int cv = it % ncv; int r = it / ncv;
-        const int sx = r % nstrips, oy = r / nstrips;
-        float acc[SW][8];
-        {
-            f32x4 b0 = *reinterpret_cast<const f32x4*>(bl + (0 * ncv + cv) * 4);
-            f32x4 b1 = *reinterpret_cast<const f32x4*>(bl + (1 * ncv + cv) * 4);
-#pragma unroll
-            for (int o = 0; o < SW; ++o)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { acc[o][j] = b0[j]; acc[o][4 + j] = b1[j]; }
-        }
-#pragma unroll 1
-        for (int ky = 0; ky < K; ++ky) {
-            float wr[K][8];
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + (((ky * K + kx) * 2 + 0) * ncv + cv) * 4);
-                f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + (((ky * K + kx) * 2 + 1) * ncv + cv) * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { wr[kx][j] = w0[j]; wr[kx][4 + j] = w1[j]; }
-            }
-            const V8<T>* row = tile + ((oy * S + ky) * IW + sx * SW * S) * ncv + cv;
-#pragma unroll
-            for (int ix = 0; ix < IWS; ++ix) {
-                Vec8f v = load8(reinterpret_cast<const T*>(row + ix * ncv));
-#pragma unroll
-                for (int o = 0; o < SW; ++o) {
-                    const int kx = ix - o * S;
-                    if (kx >= 0 && kx < K) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[o][j] = fmaf(v.v[j], wr[kx][j], acc[o][j]);
-                    }
-                }
-            }
-        }
-        const int gy = oy0 + oy;
-        if (gy < a.Ho) {
-            f32x4 s0, s1;
-            if (a.act == FR_ACT_PRELU) {
-                s0 = *reinterpret_cast<const f32x4*>(bl + ncv * 8 + (0 * ncv + cv) * 4);
-                s1 = *reinterpret_cast<const f32x4*>(bl + ncv * 8 + (1 * ncv + cv) * 4);
-            }
-#pragma unroll
-            for (int o = 0; o < SW; ++o) {
-                const int gx = ox0 + sx * SW + o;
-                if (gx < a.Wo) {
-                    Vec8f v;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float slope = 0.f;
-                        if (a.act == FR_ACT_PRELU) slope = j < 4 ? s0[j & 3] : s1[j & 3];
-                        v.v[j] = apply_act(acc[o][j], a.act, slope);
-                    }
-                    store8(Y + (((long)n * a.Ho + gy) * a.Wo + gx) * a.C + (cv0 + cv) * 8, v);
-                }
-            }
-        }
-    }
+    dw_compute<T, K, S>(a, tile, wl, bl, n, oy0, ox0, cv0, ncv, IW);
 }
 
 static size_t dw_lds_bytes(bool f32, int k, int s, int TH, int TW, int CBV) {

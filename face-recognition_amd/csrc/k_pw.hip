@@ -127,6 +127,106 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     }
 }
 
+
+// ---- streaming variant: all weights (+bias/slope) resident in LDS, K <= 128, bf16 input.
+// Each wave owns MT consecutive 32-pixel tiles per iteration and issues ALL their activation (and
+// residual) loads before the first MFMA, so that >= 2-4 KB per wave are in flight: the op is pure
+// HBM streaming and bytes in flight per CU, not arithmetic, set its speed.
+template <typename TOut, int NTB, int MT>
+__global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a) {
+    constexpr int KSM = 8 / MT;                     // max k-steps
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = lane & 31, h = lane >> 5;
+    const int t0 = blockIdx.y * NTB;
+    const int nt = min(NTB, a.NT - t0);
+    const int KS = a.KS;
+    bf16x8* wl = reinterpret_cast<bf16x8*>(smem);                         // [nt][KS][64]
+    float* bl = reinterpret_cast<float*>(smem + (size_t)NTB * KS * 1024);  // [NTB*32] bias, then slope
+    {
+        const int total = nt * KS * 64;
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.w) + (size_t)t0 * KS * 64;
+        for (int i = threadIdx.x; i < total; i += 256) reinterpret_cast<u32x4*>(smem)[i] = src[i];
+        for (int i = threadIdx.x; i < nt * 32; i += 256) {
+            bl[i] = a.e.bias[t0 * 32 + i];
+            bl[NTB * 32 + i] = a.e.slope ? a.e.slope[t0 * 32 + i] : 0.f;
+        }
+    }
+    __syncthreads();
+    const bf16* X = reinterpret_cast<const bf16*>(a.x);
+    const TOut* R = reinterpret_cast<const TOut*>(a.e.residual);
+    TOut* Y = reinterpret_cast<TOut*>(a.e.y);
+    const long per_iter = 128L * MT;
+    const long n_iter = (a.M + per_iter - 1) / per_iter;
+    const int cout = a.e.cout;
+
+    for (long it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        const long mbase = it * per_iter + (long)wave * 32 * MT + p;
+        bf16x8 xf[MT][KSM];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const long m = mbase + mt * 32;
+            const long mc = m < a.M ? m : a.M - 1;
+            const bf16* xrow = X + mc * (long)a.K;
+            const float* serow = a.se ? a.se + (mc / a.HW) * (long)a.K : nullptr;
+#pragma unroll
+            for (int s = 0; s < KSM; ++s) {
+                const int kk = s * 16 + 8 * h;
+                if (s < KS && kk < a.K) {
+                    if (serow) {
+                        Vec8f x = load8(xrow + kk), sc = load8(serow + kk);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x.v[i] *= sc.v[i];
+                        xf[mt][s] = to_frag(x);
+                    } else {
+                        xf[mt][s] = *reinterpret_cast<const bf16x8*>(xrow + kk);
+                    }
+                } else {
+                    xf[mt][s] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const long m = mbase + mt * 32;
+            const bool m_ok = m < a.M;
+#pragma unroll
+            for (int t = 0; t < NTB; ++t) {
+                if (t < nt) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KSM; ++s)
+                        if (s < KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[(t * KS + s) * 64 + lane], xf[mt][s], acc, 0, 0, 0);
+                    if (m_ok) {
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const int cl = t * 32 + 16 * h + 8 * g;          // channel within this block's tiles
+                            const int c = t0 * 32 + cl;
+                            if (c < cout) {
+                                Vec8f v;
+                                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl + cl);
+                                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bl + cl + 4);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { v.v[i] = acc[8 * g + i] + b0[i]; v.v[4 + i] = acc[8 * g + 4 + i] + b1[i]; }
+                                act8(v, a.e.act, bl + NTB * 32 + cl);
+                                const long off = m * (long)cout + c;
+                                if (R) {
+                                    const Vec8f r = load8(R + off);
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
+                                }
+                                store8(Y + off, v);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks) {
     const int ns = in_f32 ? 2 : 1;
     const int cap = 4;
@@ -139,8 +239,32 @@ void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks) {
     *chunk_ks = ck;
 }
 
+template <typename TOut, int NTB>
+static int launch_pw_stream(const PwArgs& a, hipStream_t st) {
+    const int mt = a.KS <= 2 ? 4 : (a.KS <= 4 ? 2 : 1);
+    const long per_iter = 128L * mt;
+    const long n_iter = (a.M + per_iter - 1) / per_iter;
+    dim3 grid((unsigned)std::min<long>(n_iter, 2048), (unsigned)cdiv(a.NT, NTB));
+    const size_t lds = (size_t)NTB * a.KS * 1024 + (size_t)NTB * 256;
+    if (mt == 4) hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 4>), grid, dim3(256), lds, st, a);
+    else if (mt == 2) hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 2>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 1>), grid, dim3(256), lds, st, a);
+    FR_LAUNCH_CHECK("pw_stream_kernel");
+    return FR_OK;
+}
+
 template <typename TIn, typename TOut>
 static int launch_pw_t(const PwArgs& a, int ntb, hipStream_t st) {
+    if constexpr (std::is_same<TIn, bf16>::value) {
+        if (a.KS <= 8 && a.chunk_ks >= a.KS) {
+            switch (ntb) {
+                case 1: return launch_pw_stream<TOut, 1>(a, st);
+                case 2: return launch_pw_stream<TOut, 2>(a, st);
+                case 4: return launch_pw_stream<TOut, 4>(a, st);
+                default: break;
+            }
+        }
+    }
     constexpr int NS = std::is_same<TIn, float>::value ? 2 : 1;
     const long n_super = (a.M + 127) / 128;
     dim3 grid((unsigned)std::min<long>(n_super, 2048), (unsigned)cdiv(a.NT, ntb));

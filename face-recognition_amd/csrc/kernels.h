@@ -29,6 +29,17 @@ struct DwArgs {
 };
 int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st);
 
+// ---- fused expand 1x1 (+BN+act) -> depthwise KxK (+BN+act); dw.x is the block input [N,H,W,Cin]
+struct XdwArgs {
+    DwArgs dw;
+    const bf16* we;       // expand weights, packed as for the pointwise kernel [NT][KS][NS][64][8]
+    const float* bias_e;  // [cexp_pad32]
+    const float* slope_e; // [cexp_pad32] or NULL
+    int act_e, Cin, KS;
+};
+int launch_xdw(bool f32, int k, int stride, XdwArgs a, hipStream_t st);
+bool xdw_supported(int Cin, int k, int stride);
+
 // ---- 3x3 stem conv, Cin = 3, fp32 NCHW in -> NHWC out, MFMA with K = 27 (padded to 32)
 struct StemArgs {
     const float* x;       // [N,3,H,W]

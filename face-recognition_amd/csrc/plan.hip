@@ -36,6 +36,8 @@ struct Layer {
     int K = 0, KS = 0, NT = 0, chunk_ks = 0;       // GEMM geometry
     int K2 = 0, KS2 = 0, NT2 = 0, chunk_ks2 = 0;   // SE fc2 geometry
     bool via_conv = false;                // Linear routed through the conv implicit-GEMM kernel
+    bool fused_next = false;              // expand 1x1 conv computed inside the next (depthwise) layer's kernel
+    int fuse_src = -1;                    // depthwise layer: index of the expand conv fused into it
 };
 
 }  // namespace
@@ -295,6 +297,8 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
                               int precision, fr_plan** out_plan) {
     if (!descs || n <= 0 || !out_plan || in_c <= 0 || in_h <= 0 || in_w <= 0)
         FR_FAIL(FR_ERR_ARG, "fr_plan_create: bad arguments");
+    const bool no_fuse = (precision & FR_PLAN_NO_FUSE) != 0;
+    precision &= ~FR_PLAN_NO_FUSE;
     if (precision != FR_PREC_BF16 && precision != FR_PREC_F32) FR_FAIL(FR_ERR_ARG, "fr_plan_create: bad precision");
     std::unique_ptr<fr_plan> pl(new fr_plan);
     pl->prec = precision; pl->in_c = in_c; pl->in_h = in_h; pl->in_w = in_w;
@@ -322,13 +326,27 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         if (L.residual == -1 && false) {}
     }
     last_use[n - 1] = n;   // final output stays live
+    // expand(1x1) -> depthwise fusion: the expanded tensor never leaves LDS (k_xdw.hip)
+    for (int i = 0; !no_fuse && i + 1 < n; ++i) {
+        Layer& E = pl->layers[i];
+        Layer& D = pl->layers[i + 1];
+        if (E.kind == K_PW && E.residual < 0 && D.kind == K_DW && D.src == i && last_use[i] == i + 1 &&
+            !(E.src >= 0 && pl->layers[E.src].kind == K_SE) && xdw_supported(E.K, D.k, D.stride)) {
+            E.fused_next = true;
+            D.fuse_src = i;
+            if (E.src >= 0) last_use[E.src] = std::max(last_use[E.src], i + 1);
+            else if (need_input_copy) input_last_use = std::max(input_last_use, i + 1);
+        }
+    }
     std::vector<size_t>& sizes = pl->slot_bytes;
     std::vector<char> busy;
     if (need_input_copy) pl->input_slot = alloc_slot(sizes, busy, (size_t)in_c * in_h * in_w * pl->act_bytes());
     int launches = need_input_copy ? 1 : 0;
     for (int i = 0; i < n; ++i) {
         Layer& L = pl->layers[i];
-        if (L.kind == K_SE) {
+        if (L.fused_next) {
+            L.slot = -1;
+        } else if (L.kind == K_SE) {
             L.slot_pool = alloc_slot(sizes, busy, (size_t)L.cin * 4);
             L.slot_hidden = alloc_slot(sizes, busy, (size_t)L.cout * 4);
             L.slot = alloc_slot(sizes, busy, (size_t)L.cin * 4);
@@ -339,8 +357,8 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         }
         if (L.kind == K_SE) { busy[L.slot_pool] = 0; busy[L.slot_hidden] = 0; }
         for (int j = 0; j < i; ++j)
-            if (last_use[j] == i) busy[pl->layers[j].slot] = 0;
-        if (last_use[i] < 0) busy[L.slot] = 0;            // dead output (only reachable through taps)
+            if (last_use[j] == i && pl->layers[j].slot >= 0) busy[pl->layers[j].slot] = 0;
+        if (last_use[i] < 0 && L.slot >= 0) busy[L.slot] = 0;   // dead output (only reachable through taps)
         if (need_input_copy && input_last_use == i) busy[pl->input_slot] = 0;
     }
     pl->launches = launches + (pl->layers.back().kind == K_LINEAR ? 0 : 1);
@@ -399,6 +417,11 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
     for (int i = 0; i < nl; ++i) {
         const Layer& L = plan->layers[i];
         const bool last = (i == nl - 1);
+        if (L.fused_next) {
+            if (i == tap_layer) FR_FAIL(FR_ERR_ARG, "fr_embed_tap: this layer is fused into the next one (create the plan with FR_PLAN_NO_FUSE)");
+            if (events) FR_HIP_CHECK(hipEventRecord(events[i + 1], st));
+            continue;
+        }
         void* y = (last && L.kind == K_LINEAR) ? (void*)out : (void*)base[L.slot];
         const void* xin = nullptr;
         const float* se = nullptr;
@@ -449,7 +472,16 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
                 DwArgs a{};
                 a.x = xin; a.w = L.w_f32; a.bias = L.bias; a.slope = L.slope; a.y = y;
                 a.N = N; a.H = L.inH; a.W = L.inW; a.C = L.C; a.Ho = L.H; a.Wo = L.W; a.pad = L.pad; a.act = L.act;
-                rc = launch_dw(L.in_f32, L.k, L.stride, a, st);
+                if (L.fuse_src >= 0) {
+                    const Layer& E = plan->layers[L.fuse_src];
+                    XdwArgs xa{};
+                    xa.dw = a;
+                    xa.dw.x = E.src < 0 ? in_nhwc : (const void*)base[plan->layers[E.src].slot];
+                    xa.we = E.w_packed; xa.bias_e = E.bias; xa.slope_e = E.slope; xa.act_e = E.act; xa.Cin = E.K; xa.KS = E.KS;
+                    rc = launch_xdw(L.in_f32, L.k, L.stride, xa, st);
+                } else {
+                    rc = launch_dw(L.in_f32, L.k, L.stride, a, st);
+                }
                 break;
             }
             case K_GDW: {

@@ -29,6 +29,12 @@ def default_precision() -> str:
     return os.environ.get("FR_PRECISION", "bf16")
 
 
+def default_fuse() -> bool:
+    """Expand->depthwise fusion (k_xdw.hip) is correct (bit-identical) but currently slower than the
+    two separate kernels on MI355X, so it is opt-in: env FR_FUSE=1."""
+    return os.environ.get("FR_FUSE", "0") == "1"
+
+
 def _make_divisible(v: float, divisor: int = 8) -> int:
     """utils/layers.py:6-12."""
     new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
@@ -145,7 +151,7 @@ class HipBackbone(nn.Module):
 
     def __init__(self) -> None:
         super().__init__()
-        self._plans: Dict[Tuple[int, str], "_Plan"] = {}
+        self._plans: Dict[Tuple[int, str, bool], "_Plan"] = {}
 
     # -- lowering ------------------------------------------------------------------------------
     def lower(self, g: _Graph) -> None:  # pragma: no cover - overridden
@@ -170,33 +176,34 @@ class HipBackbone(nn.Module):
         self.invalidate()
         return super().load_state_dict(*a, **kw)
 
-    def plan(self, device: torch.device, precision: Optional[str] = None) -> "_Plan":
+    def plan(self, device: torch.device, precision: Optional[str] = None, fuse: Optional[bool] = None) -> "_Plan":
         prec = precision or self.precision or default_precision()
+        fuse = default_fuse() if fuse is None else fuse
         if prec not in _lib.PRECISIONS:
             raise ValueError(f"unknown precision '{prec}' (expected one of {list(_lib.PRECISIONS)})")
-        key = (device.index if device.index is not None else torch.cuda.current_device(), prec)
+        key = (device.index if device.index is not None else torch.cuda.current_device(), prec, bool(fuse))
         if key not in self._plans:
             g = _Graph()
             self.lower(g)
-            self._plans[key] = _Plan(g, key[0], prec)
+            self._plans[key] = _Plan(g, key[0], prec, fuse)
         return self._plans[key]
 
-    def forward(self, x: torch.Tensor, precision: Optional[str] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, precision: Optional[str] = None, fuse: Optional[bool] = None) -> torch.Tensor:
         if self.training:
             raise RuntimeError("HipBackbone runs inference only: call .eval() first (reference: inference.py:92)")
         if not x.is_cuda:
             raise RuntimeError("HipBackbone.forward needs a GPU tensor: the hot path has no CPU fallback")
         if x.dim() != 4 or tuple(x.shape[1:]) != (3, 112, 112):
             raise ValueError(f"expected input [N,3,112,112], got {tuple(x.shape)}")
-        return self.plan(x.device, precision).run(x)
+        return self.plan(x.device, precision, fuse).run(x)
 
     def forward_tap(self, x: torch.Tensor, layer: int, precision: Optional[str] = None):
         """(embedding, output of plan layer ``layer`` as fp32 NCHW) -- parity tests."""
-        return self.plan(x.device, precision).run(x, tap=layer)
+        return self.plan(x.device, precision, fuse=False).run(x, tap=layer)
 
 
 class _Plan:
-    def __init__(self, g: _Graph, device_index: int, precision: str) -> None:
+    def __init__(self, g: _Graph, device_index: int, precision: str, fuse: bool = True) -> None:
         self.lib = _lib.lib()
         self.device = torch.device("cuda", device_index)
         self.names = list(g.names)
@@ -206,7 +213,7 @@ class _Plan:
         arr = (_lib.LayerDesc * self.n_layers)(*g.descs)
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.fr_plan_create(arr, self.n_layers, 3, 112, 112, _lib.PRECISIONS[precision],
+            _lib.check(self.lib.fr_plan_create(arr, self.n_layers, 3, 112, 112, _lib.PRECISIONS[precision] | (0 if fuse else _lib.FR_PLAN_NO_FUSE),
                                                C.byref(handle)), "fr_plan_create")
         self.handle = handle
         self._ws: Optional[torch.Tensor] = None

@@ -35,6 +35,9 @@ typedef enum fr_status {
  * FR_PREC_F32 : activations stored fp32; GEMM operands split hi+lo bf16, three MFMA passes
  *               (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo), fp32 accumulate (~16 mantissa bits). */
 typedef enum fr_precision { FR_PREC_BF16 = 0, FR_PREC_F32 = 1 } fr_precision;
+/* OR into `precision`: keep every layer a separate launch (no expand->depthwise fusion), so that
+ * fr_embed_tap can observe every intermediate tensor. */
+#define FR_PLAN_NO_FUSE 0x100
 
 typedef enum fr_op { FR_OP_CONV = 0, FR_OP_SE = 1, FR_OP_LINEAR = 2 } fr_op;
 typedef enum fr_act { FR_ACT_NONE = 0, FR_ACT_PRELU = 1, FR_ACT_HSWISH = 2,
