@@ -44,27 +44,45 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     const TIn* X = reinterpret_cast<const TIn*>(a.x);
     const bf16* Wp = a.w + (size_t)nt0 * KS * NS * BN * 32;       // [ks][NS][BN][32]
 
+    // Hoisted addressing: the centre-pixel pointer and a 9-bit per-tap validity mask are computed once
+    // per thread; inside the K loop a slice only adds wave-uniform (scalar) offsets.
+    const unsigned char* xc = reinterpret_cast<const unsigned char*>(
+        X + (((long)sn * a.H + (long)soy * a.stride) * a.W + (long)sox * a.stride) * a.Cin + shalf * 16);
+    unsigned tapmask = 0;
+    for (int t = 0; t < a.ksize * a.ksize; ++t) {
+        const int ky = t / a.ksize, kx = t - ky * a.ksize;
+        const int iy = soy * a.stride + ky - a.pad, ix = sox * a.stride + kx - a.pad;
+        if (spix_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) tapmask |= 1u << t;
+    }
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(Wp + (size_t)srow * 32 + shalf * 16);
+    constexpr long W_SLICE = (long)NS * BN * 32 * 2;                 // bytes of packed weights per slice
+    // scalar slice cursor (tap, chunk) advanced once per prefetch
+    int cur_tap = 0, cur_chunk = 0, cur_ky = 0, cur_kx = 0;
+    long cur_w = 0;
+
     u32x4 pa[NS][2], pb[SPLIT ? 4 : 2];
-    auto prefetch = [&](int ks) {
+    auto prefetch = [&](int) {
         if (srow < BN) {
 #pragma unroll
             for (int sp = 0; sp < NS; ++sp) {
-                const bf16* src = Wp + ((size_t)(ks * NS + sp) * BN + srow) * 32 + shalf * 16;
+                const unsigned char* src = wsrc + cur_w + (long)sp * BN * 64;
                 pa[sp][0] = *reinterpret_cast<const u32x4*>(src);
-                pa[sp][1] = *reinterpret_cast<const u32x4*>(src + 8);
+                pa[sp][1] = *reinterpret_cast<const u32x4*>(src + 16);
             }
         }
-        const int tap = ks / chunks, c0 = (ks - tap * chunks) << 5;
-        const int ky = tap / a.ksize, kx = tap - ky * a.ksize;
-        const int iy = soy * a.stride + ky - a.pad, ix = sox * a.stride + kx - a.pad;
-        const bool ok = spix_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        if (ok) {
-            const TIn* src = X + (((long)sn * a.H + iy) * a.W + ix) * a.Cin + c0 + shalf * 16;
+        const long toff = (((long)(cur_ky - a.pad) * a.W + (cur_kx - a.pad)) * a.Cin + (cur_chunk << 5)) * (long)sizeof(TIn);
+        if ((tapmask >> cur_tap) & 1u) {
+            const unsigned char* src = xc + toff;
 #pragma unroll
-            for (int i = 0; i < (SPLIT ? 4 : 2); ++i) pb[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(src) + 16 * i);
+            for (int i = 0; i < (SPLIT ? 4 : 2); ++i) pb[i] = *reinterpret_cast<const u32x4*>(src + 16 * i);
         } else {
 #pragma unroll
             for (int i = 0; i < (SPLIT ? 4 : 2); ++i) pb[i] = u32x4{0, 0, 0, 0};
+        }
+        cur_w += W_SLICE;
+        if (++cur_chunk == chunks) {
+            cur_chunk = 0; ++cur_tap;
+            if (++cur_kx == a.ksize) { cur_kx = 0; ++cur_ky; }
         }
     };
     auto commit = [&](int buf) {
@@ -154,6 +172,138 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     }
 }
 
+
+// ---- bf16 path: LDS-DMA staging (global_load_lds, 16 B per lane) --------------------------------
+// The register-staged kernel above is LDS-write bound (ds_write_b128 moves ~79 B/clk/CU); here both
+// operand tiles go global -> LDS directly.  One wave instruction writes 1 KiB linearly = 16 rows of
+// 64 B, so the bank-conflict swizzle is applied on the SOURCE side (lane (row, c) fetches logical
+// chunk c ^ ((row>>2)&3)) and undone on the fragment read.  Out-of-image lanes fetch from a zero
+// page.  Double-buffered; one vmcnt(0)+barrier per K slice, hidden by 3-4 co-resident blocks.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <typename TOut, int TI, int TJ, int WM, int WN, int BK>
+__global__ __launch_bounds__(256) void conv_glds_kernel(ConvArgs a) {
+    constexpr int BN = 32 * TI * WM, BM = 32 * TJ * WN;
+    static_assert(WM * WN == 4 && BM == 128, "4 waves, 128 pixels per block");
+    static_assert(BK == 32 || BK == 64, "K slice of 32 or 64 channels");
+    constexpr int ROWB = BK * 2;                      // bytes per LDS row
+    constexpr int CR = BK / 8;                        // 16-byte chunks per row
+    constexpr int RG = 64 / CR;                       // rows written by one wave instruction (1 KiB)
+    constexpr int A_BYTES = BN * ROWB, B_BYTES = BM * ROWB, BUF = A_BYTES + B_BYTES;
+    constexpr int GA = BN / RG / 4, GB = BM / RG / 4; // groups per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // bank swizzle of row r: the 16 rows of a ds_read_b128 lane group must hit 16 distinct 16-B slots
+    auto swz = [](int row) { return BK == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int p = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const long m0 = (long)blockIdx.x * BM;
+    const int nt0 = blockIdx.y;
+    const int chunks = a.Cin / BK;
+    const int KS = a.ksize * a.ksize * chunks;
+
+    const int sub = lane / CR, pc = lane % CR;
+    const unsigned char* wsrc[GA];
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+        const int row = RG * (wave + 4 * j) + sub;
+        const int lc = pc ^ swz(row);
+        wsrc[j] = reinterpret_cast<const unsigned char*>(a.w) + ((size_t)nt0 * KS * BN + row) * ROWB + lc * 16;
+    }
+    const unsigned char* xc[GB];
+    unsigned tapmask[GB];
+    const bf16* X = reinterpret_cast<const bf16*>(a.x);
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+        const int row = RG * (wave + 4 * j) + sub;
+        const int lc = pc ^ swz(row);
+        const long pix = m0 + row;
+        const bool ok = pix < a.M;
+        int sn = 0, soy = 0, sox = 0;
+        if (ok) { const int hw = a.Ho * a.Wo; sn = (int)(pix / hw); const int r = (int)(pix - (long)sn * hw); soy = r / a.Wo; sox = r - soy * a.Wo; }
+        xc[j] = reinterpret_cast<const unsigned char*>(
+            X + (((long)sn * a.H + (long)soy * a.stride) * a.W + (long)sox * a.stride) * a.Cin) + lc * 16;
+        unsigned mask = 0;
+        for (int t = 0; t < a.ksize * a.ksize; ++t) {
+            const int ky = t / a.ksize, kx = t - ky * a.ksize;
+            const int iy = soy * a.stride + ky - a.pad, ix = sox * a.stride + kx - a.pad;
+            if (ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) mask |= 1u << t;
+        }
+        tapmask[j] = mask;
+    }
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(a.zeros);
+    int cur_tap = 0, cur_chunk = 0, cur_ky = 0, cur_kx = 0;
+    long cur_w = 0;
+
+    auto stage = [&](int buf) {
+        unsigned char* base = smem + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < GA; ++j)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[j] + cur_w), (lds_ptr_t)(base + (wave + 4 * j) * 1024), 16, 0, 0);
+        const long toff = (((long)(cur_ky - a.pad) * a.W + (cur_kx - a.pad)) * a.Cin + cur_chunk * BK) * 2;
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+            const unsigned char* src = ((tapmask[j] >> cur_tap) & 1u) ? xc[j] + toff : zsrc;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + A_BYTES + (wave + 4 * j) * 1024), 16, 0, 0);
+        }
+        cur_w += (long)BN * ROWB;
+        if (++cur_chunk == chunks) {
+            cur_chunk = 0; ++cur_tap;
+            if (++cur_kx == a.ksize) { cur_kx = 0; ++cur_ky; }
+        }
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets: logical chunk 2s+h sits at physical (2s+h)^sw = (h^sw) ^ 2s
+    int aoff[TI], boff[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) { const int row = (wm * TI + i) * 32 + p; aoff[i] = row * ROWB + ((h ^ swz(row)) << 4); }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) { const int row = (wn * TJ + j) * 32 + p; boff[j] = A_BYTES + row * ROWB + ((h ^ swz(row)) << 4); }
+
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < KS) stage(buf ^ 1);
+        const unsigned char* bb = smem + buf * BUF;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 af[TI], bfr[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(bb + (aoff[i] ^ (s << 5)));
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(bb + (boff[j] ^ (s << 5)));
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const long m = m0 + (wn * TJ + j) * 32 + p;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+            epilogue_store<TOut>(acc[i][j], a.e, m, nt0 * BN + (wm * TI + i) * 32 + 16 * h, m < a.M);
+    }
+}
+
 int conv_block_couts(int cout) { return cout >= 128 ? 128 : 64; }
 
 template <typename TIn, typename TOut>
@@ -161,6 +311,20 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     constexpr int NS = std::is_same<TIn, float>::value ? 2 : 1;
     const int bn = conv_block_couts(a.e.cout);
     dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)cdiv(a.e.cout, bn));
+    if constexpr (std::is_same<TIn, bf16>::value) {
+        if (a.zeros) {
+            const size_t lds = 2 * (size_t)(bn + 128) * a.bk * 2;
+            if (a.bk == 64) {
+                if (bn == 128) hipLaunchKernelGGL((conv_glds_kernel<TOut, 2, 2, 2, 2, 64>), grid, dim3(256), lds, st, a);
+                else hipLaunchKernelGGL((conv_glds_kernel<TOut, 2, 1, 1, 4, 64>), grid, dim3(256), lds, st, a);
+            } else {
+                if (bn == 128) hipLaunchKernelGGL((conv_glds_kernel<TOut, 2, 2, 2, 2, 32>), grid, dim3(256), lds, st, a);
+                else hipLaunchKernelGGL((conv_glds_kernel<TOut, 2, 1, 1, 4, 32>), grid, dim3(256), lds, st, a);
+            }
+            FR_LAUNCH_CHECK("conv_glds_kernel");
+            return FR_OK;
+        }
+    }
     const size_t lds = 2 * (size_t)NS * (bn + 128) * CV_ROW;
     if (bn == 128) {
         auto k = conv_gemm_kernel<TIn, TOut, 2, 2, 2, 2>;
@@ -175,7 +339,7 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
 }
 
 int launch_conv(bool in_f32, bool out_f32, const ConvArgs& a, hipStream_t st) {
-    if (a.Cin % 32 || a.e.cout % 8 || a.M <= 0 || (a.ksize != 1 && a.ksize != 3))
+    if (a.Cin % 32 || a.Cin % a.bk || (a.bk != 32 && a.bk != 64) || (in_f32 && a.bk != 32) || a.e.cout % 8 || a.M <= 0 || (a.ksize != 1 && a.ksize != 3))
         FR_FAIL(FR_ERR_ARG, "conv: Cin must be a multiple of 32, Cout of 8, ksize 1 or 3");
     if ((a.M + 127) / 128 > 0x7FFFFFFFL) FR_FAIL(FR_ERR_ARG, "conv: grid too large");
     if (in_f32 && out_f32) return launch_conv_t<float, float>(a, st);

@@ -5,21 +5,23 @@
 // of MarginCosineProduct (utils/metrics.py:18-28: normalised embeddings x normalised matrix^T) and
 // calculate_accuracy's topk (utils/general.py:102-116).  Oracle: oracle/search.py.
 //
-// Kernel: a block owns 128 queries, kept in LDS for its whole life (128 x 512 bf16, rows padded
-// by 16 B so ds_read_b128 is bank-conflict free), and streams its gallery split in 128-row tiles,
-// 32 k-columns at a time, double-buffered through registers.  4 waves in a 2x2 arrangement; each
-// wave computes a 64 (gallery) x 64 (query) tile as 2x2 v_mfma_f32_32x32x16_bf16 tiles with the
-// gallery as the "A" operand, so that accumulator columns are queries: every lane owns ONE query
-// per n-tile and sees 32 gallery scores for it, and keeps a private sorted top-k list in
-// registers (strict '>' insert => ties stay with the lower index).  Lists of the lanes / waves /
-// gallery splits that share a query are merged by topk_select_kernel.
+// Kernel: 4 waves in a 2x2 arrangement; each wave computes a 64 (gallery) x 64 (query) tile as 2x2
+// v_mfma_f32_32x32x16_bf16 tiles with the gallery as the "A" operand, so that accumulator columns
+// are queries: every lane owns ONE query per n-tile, sees 32 gallery scores for it per tile, and
+// keeps a private sorted top-k list in registers (strict '>' insert => ties stay with the lower
+// index).  Lists of the lanes / waves / gallery splits that share a query are merged by
+// topk_select_kernel.
 #include "kernels.h"
 
 #define SEARCH_D 512
 #define SEARCH_KMAX 8
-#define Q_STRIDE (SEARCH_D * 2 + 16)     // bytes per query row in LDS
-#define G_STRIDE (32 * 2 + 16)           // bytes per gallery row slice in LDS
 #define SEARCH_LISTS 4                   // lists per query per split: 2 wave rows x 2 lane halves
+#define S_BK 64                          // K slice (bf16 elements) staged per barrier
+#define S_ROWB (S_BK * 2)
+#define S_TILE_BYTES (128 * S_ROWB)      // one operand tile: 128 rows x 128 B
+#define S_BUF (2 * S_TILE_BYTES)
+#define S_KSL (SEARCH_D / S_BK)          // slices per gallery tile
+#define S_PAD 1024                       // unused LDS bytes in front of the tiles (see lbase)
 
 struct SearchArgs {
     const bf16* q; const bf16* g;
@@ -30,24 +32,31 @@ struct SearchArgs {
     long Qpad;
 };
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// A block owns 128 queries and one gallery split; it walks the split in 128-row tiles.  Both operand
+// tiles of every 64-wide K slice go global -> LDS by LDS-DMA (global_load_lds, 16 B per lane; the
+// query slices are re-read from L2, which is what keeps LDS at 64 KB and two blocks per CU), with the
+// bank swizzle (chunk ^ ((row>>1)&7)) applied on the source address and undone on the fragment read.
+// The (tile, slice) sequence is flattened so the DMA of the next tile's first slice overlaps the last
+// MFMAs and the top-k selection of the current tile.
+// VALU diet (the first version of this loop issued 20 VALU instructions per MFMA and was VALU-bound):
+// the 8 slices of a tile are unrolled so LDS buffer offsets and the per-slice global offset are
+// immediates; row pointers are recomputed once per tile; the top-k selection first reduces each
+// 32x32 accumulator tile to a per-lane maximum (v_max3) and skips the insertion code unless some
+// lane of the wave beats its current k-th score.
 template <int KK>
 __global__ __launch_bounds__(256) void search_kernel(SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Qs = smem;                                  // 128 * Q_STRIDE
-    unsigned char* Gs = smem + 128 * Q_STRIDE;                 // 2 * 128 * G_STRIDE
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int p = lane & 31, h = lane >> 5;
     const int wg = wave >> 1, wq = wave & 1;                   // wave row (gallery), wave col (query)
     const long q0 = (long)blockIdx.x * 128;
     const int split = blockIdx.y;
-
-    // stage the query tile (rows beyond Q are clamped; their results are never read)
-    for (int i = tid; i < 128 * 64; i += 256) {
-        const int row = i >> 6, c = i & 63;
-        const long qr = min(q0 + row, a.Q - 1);
-        *reinterpret_cast<u32x4*>(Qs + row * Q_STRIDE + c * 16) =
-            *reinterpret_cast<const u32x4*>(a.q + qr * SEARCH_D + c * 8);
-    }
+    const long tile_begin = (long)split * a.tiles_per_split;
+    const long ntiles_all = (a.G + 127) / 128;
+    const long tile_end = min(tile_begin + a.tiles_per_split, ntiles_all);
 
     float ts[2][KK]; int ti[2][KK];
 #pragma unroll
@@ -55,86 +64,150 @@ __global__ __launch_bounds__(256) void search_kernel(SearchArgs a) {
 #pragma unroll
         for (int e = 0; e < KK; ++e) { ts[j][e] = -INFINITY; ti[j][e] = 0x7FFFFFFF; }
 
-    const long tile_begin = (long)split * a.tiles_per_split;
-    const long ntiles_all = (a.G + 127) / 128;
-    const long tile_end = min(tile_begin + a.tiles_per_split, ntiles_all);
-
-    // staging role: thread -> (row = tid>>1, 32-byte half = tid&1) of a 128 x 32 slice (2 x 16 B)
-    const int srow = tid >> 1, shalf = tid & 1;
-    u32x4 pre0, pre1;
-    auto prefetch = [&](long tile, int ks) {
-        const long gr = min(tile * 128 + srow, a.G - 1);
-        const bf16* src = a.g + gr * SEARCH_D + ks * 32 + shalf * 16;
-        pre0 = *reinterpret_cast<const u32x4*>(src);
-        pre1 = *reinterpret_cast<const u32x4*>(src + 8);
+    // staging role: one wave instruction = 8 rows x 128 B; this lane: row sub, physical chunk pc
+    const int sub = lane >> 3, pc = lane & 7;
+    const unsigned char* qsrc[4];
+    int grow[4], lcs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * (wave + 4 * j) + sub;
+        const int lc = pc ^ ((row >> 1) & 7);
+        lcs[j] = lc * 16;
+        grow[j] = row;
+        const long qr = min(q0 + row, a.Q - 1);
+        qsrc[j] = reinterpret_cast<const unsigned char*>(a.q + qr * SEARCH_D) + lc * 16;
+    }
+    const unsigned char* gbase = reinterpret_cast<const unsigned char*>(a.g);
+    const unsigned char* gsrc[4];
+    auto tile_ptrs = [&](long tile) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long gr = min(tile * 128 + grow[j], a.G - 1);
+            gsrc[j] = gbase + gr * (SEARCH_D * 2) + lcs[j];
+        }
     };
-    auto commit = [&](int buf) {
-        unsigned char* dst = Gs + buf * 128 * G_STRIDE + srow * G_STRIDE + shalf * 32;
-        *reinterpret_cast<u32x4*>(dst) = pre0;
-        *reinterpret_cast<u32x4*>(dst + 16) = pre1;
-    };
+    // The instruction offset of global_load_lds is added to BOTH the global and the LDS address, so the
+    // LDS base passed for slice KSI is pre-decremented by KSI*S_ROWB; the tiles start S_PAD bytes into
+    // the allocation so that this never goes below zero.
+    unsigned char* const lbase = smem + S_PAD + wave * 1024;
 
-    if (tile_begin < tile_end) { prefetch(tile_begin, 0); commit(0); }
+    // per-lane fragment offsets for the 4 k-steps of a slice
+    int aoff[2][4], boff[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wg * 64 + i * 32 + p;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) aoff[i][s] = row * S_ROWB + (((h ^ ((row >> 1) & 7)) << 4) ^ (s << 5));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = wq * 64 + j * 32 + p;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) boff[j][s] = S_TILE_BYTES + row * S_ROWB + (((h ^ ((row >> 1) & 7)) << 4) ^ (s << 5));
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define S_STAGE(BUFI, KSI)                                                                                         \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                           \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)gsrc[j_], (lds_ptr_t)(lbase + (BUFI) * S_BUF + j_ * 4096 - (KSI) * S_ROWB), \
+                                             16, (KSI) * S_ROWB, 0);                                               \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                           \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)qsrc[j_],                                                  \
+                                             (lds_ptr_t)(lbase + (BUFI) * S_BUF + S_TILE_BYTES + j_ * 4096 - (KSI) * S_ROWB), 16, \
+                                             (KSI) * S_ROWB, 0);                                                   \
+    } while (0)
+
+    if (tile_begin < tile_end) {
+        tile_ptrs(tile_begin);
+        S_STAGE(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
-    for (long tile = tile_begin; tile < tile_end; ++tile) {
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
 #pragma unroll 1
-        for (int ks = 0; ks < 16; ++ks) {
-            const int buf = ks & 1;
-            const bool more = ks < 15 || tile + 1 < tile_end;
-            if (more) { if (ks < 15) prefetch(tile, ks + 1); else prefetch(tile + 1, 0); }
-            const unsigned char* gb = Gs + buf * 128 * G_STRIDE;
+    for (long tile = tile_begin; tile < tile_end; ++tile) {
+        const bool more = tile + 1 < tile_end;
+        auto slice = [&](auto KSC) {
+            constexpr int ks = decltype(KSC)::value;
+            constexpr int buf = ks & 1;
+            if constexpr (ks + 1 < S_KSL) {
+                S_STAGE(buf ^ 1, ks + 1);
+            } else {
+                if (more) {
+                    tile_ptrs(tile + 1);
+                    S_STAGE(buf ^ 1, 0);
+                }
+            }
+            const unsigned char* bb = smem + S_PAD + buf * S_BUF;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < 4; ++s) {
                 bf16x8 af[2], bfr[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    af[i] = *reinterpret_cast<const bf16x8*>(gb + (wg * 64 + i * 32 + p) * G_STRIDE + (s * 16 + 8 * h) * 2);
+                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(bb + aoff[i][s]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    bfr[j] = *reinterpret_cast<const bf16x8*>(Qs + (wq * 64 + j * 32 + p) * Q_STRIDE + (ks * 32 + s * 16 + 8 * h) * 2);
+                for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(bb + boff[j][s]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
-            if (more) commit(buf ^ 1);
-            __syncthreads();
-        }
-
-        // selection: lane owns query column (wq*64 + j*32 + p); rows = gallery
-        const long gbase = tile * 128 + wg * 64;
+            if constexpr (ks == S_KSL - 1) {
+                // ---- selection: lane owns query column (wq*64 + j*32 + p); accumulator rows = gallery
+                const long gb = tile * 128 + wg * 64;
+                const bool partial = gb + 64 > a.G;                 // only the last tile can hold rows >= G
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+                    for (int i = 0; i < 2; ++i) {
+                        if (partial) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long grow = gbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    float s = acc[i][j][r];
-                    if (grow < a.G && s > ts[j][KK - 1]) {
-                        int gi = (int)grow;
+                            for (int r = 0; r < 16; ++r)
+                                if (gb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= a.G) acc[i][j][r] = -INFINITY;
+                        }
+                        float mx = acc[i][j][0];
 #pragma unroll
-                        for (int e = 0; e < KK; ++e) {
-                            if (s > ts[j][e]) {
-                                const float t = ts[j][e]; ts[j][e] = s; s = t;
-                                const int u = ti[j][e]; ti[j][e] = gi; gi = u;
+                        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][j][r]);
+                        if (__any(mx > ts[j][KK - 1])) {
+                            const int g0 = (int)gb + i * 32 + 4 * h;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                float s = acc[i][j][r];
+                                if (s > ts[j][KK - 1]) {
+                                    int gi = g0 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                                    for (int e = 0; e < KK; ++e) {
+                                        if (s > ts[j][e]) {
+                                            const float t = ts[j][e]; ts[j][e] = s; s = t;
+                                            const int u = ti[j][e]; ti[j][e] = gi; gi = u;
+                                        }
+                                    }
+                                }
                             }
                         }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
                     }
                 }
             }
-        }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        static_assert(S_KSL == 8, "slice unroll below assumes 8 slices per tile");
+        slice(std::integral_constant<int, 0>{}); slice(std::integral_constant<int, 1>{});
+        slice(std::integral_constant<int, 2>{}); slice(std::integral_constant<int, 3>{});
+        slice(std::integral_constant<int, 4>{}); slice(std::integral_constant<int, 5>{});
+        slice(std::integral_constant<int, 6>{}); slice(std::integral_constant<int, 7>{});
     }
+#undef S_STAGE
 
     // publish this lane's lists
 #pragma unroll
@@ -179,7 +252,7 @@ __global__ void topk_select_kernel(const float* s, const TI* idx, int nlists, lo
 
 static void search_geometry(long Q, long G, int* nsplit, long* tiles_per_split, long* Qpad) {
     const long qtiles = (Q + 127) / 128, gtiles = (G + 127) / 128;
-    long ns = (1024 + qtiles - 1) / qtiles;        // aim for >= 1024 blocks
+    long ns = (512 + qtiles - 1) / qtiles;         // aim for >= 512 blocks (2 per CU); long splits keep top-k inserts rare
     if (ns > gtiles) ns = gtiles;
     if (ns < 1) ns = 1;
     const long tps = (gtiles + ns - 1) / ns;
@@ -214,7 +287,7 @@ extern "C" int fr_topk_search(const uint16_t* q, const uint16_t* g, int64_t Q, i
     const size_t nel = (size_t)a.nsplit * SEARCH_LISTS * a.Qpad * k;
     a.part_s = reinterpret_cast<float*>(ws);
     a.part_i = reinterpret_cast<int*>(ws + nel * 4);
-    const size_t lds = 128 * Q_STRIDE + 2 * 128 * G_STRIDE;
+    const size_t lds = 2 * S_BUF + S_PAD;
     dim3 grid((unsigned)(a.Qpad / 128), (unsigned)a.nsplit);
     static bool attr_set = false;
     if (!attr_set) {

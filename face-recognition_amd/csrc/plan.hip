@@ -35,6 +35,7 @@ struct Layer {
     float* slope = nullptr;
     int K = 0, KS = 0, NT = 0, chunk_ks = 0;       // GEMM geometry
     int K2 = 0, KS2 = 0, NT2 = 0, chunk_ks2 = 0;   // SE fc2 geometry
+    int conv_bk = 32;                     // K-slice width the conv weights were packed with
     bool via_conv = false;                // Linear routed through the conv implicit-GEMM kernel
     bool fused_next = false;              // expand 1x1 conv computed inside the next (depthwise) layer's kernel
     int fuse_src = -1;                    // depthwise layer: index of the expand conv fused into it
@@ -50,6 +51,7 @@ struct fr_plan {
     int input_slot = -1;                  // NHWC copy of the network input (non-stem first layers)
     int device = 0;
     int launches = 0;
+    void* zeros = nullptr;                // 256 B of zeros (padding source of the LDS-DMA conv path)
     bool act_f32() const { return prec == FR_PREC_F32; }
     size_t act_bytes() const { return prec == FR_PREC_F32 ? 4 : 2; }
     ~fr_plan() { for (void* p : allocs) (void)hipFree(p); }
@@ -110,21 +112,21 @@ void pack_gemm_weights(const std::vector<double>& W, int cout, int K, int ns, st
 
 // Pack W(cout, tap, c) into the LDS image of conv_gemm_kernel: [cout tile][ks][NS][BN rows][32].
 template <typename F>
-void pack_conv_weights(F&& wfn, int cout, int cin, int taps, int ns, std::vector<uint16_t>& out) {
-    const int bn = conv_block_couts(cout), ntiles = cdiv(cout, bn), chunks = cin / 32, KS = taps * chunks;
-    out.assign((size_t)ntiles * KS * ns * bn * 32, 0);
+void pack_conv_weights(F&& wfn, int cout, int cin, int taps, int ns, int bk, std::vector<uint16_t>& out) {
+    const int bn = conv_block_couts(cout), ntiles = cdiv(cout, bn), chunks = cin / bk, KS = taps * chunks;
+    out.assign((size_t)ntiles * KS * ns * bn * bk, 0);
     for (int nt = 0; nt < ntiles; ++nt)
         for (int ks = 0; ks < KS; ++ks) {
-            const int tap = ks / chunks, c0 = (ks % chunks) * 32;
+            const int tap = ks / chunks, c0 = (ks % chunks) * bk;
             for (int r = 0; r < bn; ++r) {
                 const int co = nt * bn + (r / 32) * 32 + mfma_row_to_cout(r % 32);
                 if (co >= cout) continue;
-                for (int kk = 0; kk < 32; ++kk) {
+                for (int kk = 0; kk < bk; ++kk) {
                     const double w = wfn(co, tap, c0 + kk);
                     const uint16_t hi = host_f2bf((float)w);
-                    const size_t base = ((((size_t)nt * KS + ks) * ns) * bn + r) * 32 + kk;
+                    const size_t base = ((((size_t)nt * KS + ks) * ns) * bn + r) * bk + kk;
                     out[base] = hi;
-                    if (ns == 2) out[base + (size_t)bn * 32] = host_f2bf((float)(w - (double)host_bf2f(hi)));
+                    if (ns == 2) out[base + (size_t)bn * bk] = host_f2bf((float)(w - (double)host_bf2f(hi)));
                 }
             }
         }
@@ -216,8 +218,9 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
             L.kind = K_CONV3;
             std::vector<uint16_t> packed;
             const int cin = d.cin;
+            L.conv_bk = (!L.in_f32 && d.cin % 64 == 0 && d.cin >= 128) ? 64 : 32;
             pack_conv_weights([&](int co, int tap, int c) { return (double)d.weight[((size_t)co * cin + c) * 9 + tap] * scale[co]; },
-                              d.cout, d.cin, 9, L.in_f32 ? 2 : 1, packed);
+                              d.cout, d.cin, 9, L.in_f32 ? 2 : 1, L.conv_bk, packed);
             int rc = upload(pl, packed, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
         } else {
             FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "conv shape with no kernel");
@@ -272,7 +275,8 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
         int rc;
         if (K >= 4096 && K % 32 == 0) {           // SphereFace fc: K-streaming implicit-GEMM kernel
             L.via_conv = true;
-            pack_conv_weights([&](int co, int, int c) { return W[(size_t)co * K + c]; }, d.cout, K, 1, L.in_f32 ? 2 : 1, packed);
+            L.conv_bk = (!L.in_f32 && K % 64 == 0) ? 64 : 32;
+            pack_conv_weights([&](int co, int, int c) { return W[(size_t)co * K + c]; }, d.cout, K, 1, L.in_f32 ? 2 : 1, L.conv_bk, packed);
         } else {
             pack_gemm_weights(W, d.cout, K, L.in_f32 ? 2 : 1, packed, &L.KS, &L.NT);
             int ntb; pw_pick_tiling(L.in_f32, L.NT, L.KS, &ntb, &L.chunk_ks);
@@ -303,6 +307,12 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
     std::unique_ptr<fr_plan> pl(new fr_plan);
     pl->prec = precision; pl->in_c = in_c; pl->in_h = in_h; pl->in_w = in_w;
     FR_HIP_CHECK(hipGetDevice(&pl->device));
+    {
+        std::vector<uint32_t> z(64, 0u);
+        uint32_t* zp = nullptr;
+        int rc = upload(pl.get(), z, &zp); if (rc) return rc;
+        pl->zeros = zp;
+    }
     pl->layers.reserve(n);
     for (int i = 0; i < n; ++i) {
         Layer L;
@@ -447,7 +457,7 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
                 a.x = xin; a.w = L.w_packed;
                 a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act};
                 a.M = (long)N * L.H * L.W; a.H = L.inH; a.W = L.inW; a.Ho = L.H; a.Wo = L.W;
-                a.Cin = L.cin; a.ksize = 3; a.stride = L.stride; a.pad = L.pad;
+                a.Cin = L.cin; a.ksize = 3; a.stride = L.stride; a.pad = L.pad; a.zeros = plan->zeros; a.bk = L.conv_bk;
                 rc = launch_conv(L.in_f32, L.out_f32, a, st);
                 break;
             }
@@ -456,7 +466,7 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
                     ConvArgs a{};
                     a.x = xin; a.w = L.w_packed;
                     a.e = EpiArgs{L.bias, nullptr, nullptr, y, L.cout, L.act};
-                    a.M = N; a.H = a.W = a.Ho = a.Wo = 1; a.Cin = L.K; a.ksize = 1; a.stride = 1; a.pad = 0;
+                    a.M = N; a.H = a.W = a.Ho = a.Wo = 1; a.Cin = L.K; a.ksize = 1; a.stride = 1; a.pad = 0; a.zeros = plan->zeros; a.bk = L.conv_bk;
                     rc = launch_conv(L.in_f32, true, a, st);
                     break;
                 }
