@@ -47,7 +47,7 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // 32x32 accumulator tile to a per-lane maximum (v_max3) and skips the insertion code unless some
 // lane of the wave beats its current k-th score.
 template <int KK>
-__global__ __launch_bounds__(256) void search_kernel(SearchArgs a) {
+__global__ __launch_bounds__(256, 2) void search_kernel(SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int p = lane & 31, h = lane >> 5;
