@@ -52,6 +52,24 @@ def layer_alg_bytes(plan, batch):
     return out
 
 
+def layer_alg_flops(plan, batch):
+    """2 x MACs of every plan layer; SE = its two 1x1 convs."""
+    out = []
+    for i in range(plan.n_layers):
+        c, h, w = plan.dims[i]
+        cin, cout, k, groups = plan.descs_ck[i]
+        if plan.ops[i] == 1:
+            macs = 2 * cin * cout
+        elif plan.ops[i] == 2:
+            src = plan.srcs[i]
+            ci, hi, wi = (3, 112, 112) if src < 0 else plan.dims[src]
+            macs = ci * hi * wi * cout
+        else:
+            macs = cout * (cin // groups) * k * k * h * w
+        out.append(2.0 * macs * batch)
+    return out
+
+
 def cpu_baseline(model_name, seconds=15.0):
     from oracle import backbones as ob
     net = ob.seeded(model_name, 0)
@@ -153,11 +171,13 @@ def main():
     ms = dt / a.steps * 1e3
     value = a.batch * a.steps * world / dt
 
+    cfg_name = {("mobilenetv3_large", 1024): "BASELINE.json configs[1]", ("sphere64", 512): "BASELINE.json configs[2]"}.get(
+        (a.model, a.batch), "not a BASELINE.json config")
     line = {"metric": "embeddings/sec", "value": round(value, 1), "unit": "embeddings/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": f"{a.model} batch-{a.batch} {a.precision} embedding extraction, 112x112 synthetic faces, "
-                                   "random-init weights (BASELINE.json configs[1])",
+                                   f"random-init weights ({cfg_name})",
                        "global_batch": a.batch * world, "parallelism": f"replicas x{world} (no collective)"}}
 
     if rank == 0:
@@ -165,6 +185,7 @@ def main():
         plan = model.plan(dev)
         g = fr.models._Graph(); model.lower(g)
         plan.descs_cio = [(int(d.cin), int(d.cout)) for d in g.descs]
+        plan.descs_ck = [(int(d.cin), int(d.cout), int(d.kernel), max(1, int(d.groups))) for d in g.descs]
         reps = 5
         acc = None
         for _ in range(reps):
@@ -172,17 +193,26 @@ def main():
             acc = [r[2] for r in rows] if acc is None else [p + r[2] for p, r in zip(acc, rows)]
         ms_layer = [v / reps for v in acc]
         alg = layer_alg_bytes(plan, a.batch)
+        flp = layer_alg_flops(plan, a.batch)
         fam = {}
-        for (name, kern, _, _), t, b in zip(rows, ms_layer, alg):
-            f = fam.setdefault(kern, [0.0, 0.0, 0])
-            f[0] += t; f[1] += b; f[2] += 1
+        for (name, kern, _, _), t, b, fl in zip(rows, ms_layer, alg, flp):
+            f = fam.setdefault(kern, [0.0, 0.0, 0, 0.0])
+            f[0] += t; f[1] += b; f[2] += 1; f[3] += fl
         dom = max(fam, key=lambda k: fam[k][0])
-        t_dom, b_dom, n_dom = fam[dom]
-        ach = b_dom / (t_dom * 1e-3) / 1e9
-        line["roofline"] = {"bound": "hbm", "kernel": dom, "launches_per_step": n_dom,
-                            "avg_launch_ms": round(t_dom / n_dom, 4), "alg_bytes_per_launch": int(b_dom / n_dom),
-                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        t_dom, b_dom, n_dom, f_dom = fam[dom]
+        # arithmetic intensity of the dominant family against the machine balance decides the bound
+        if f_dom / b_dom > MFMA_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9):
+            ach = f_dom / (t_dom * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": n_dom,
+                                "avg_launch_ms": round(t_dom / n_dom, 4), "alg_flops_per_launch": int(f_dom / n_dom),
+                                "achieved": round(ach, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": None}
+        else:
+            ach = b_dom / (t_dom * 1e-3) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": dom, "launches_per_step": n_dom,
+                                "avg_launch_ms": round(t_dom / n_dom, 4), "alg_bytes_per_launch": int(b_dom / n_dom),
+                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
         if a.model in ALG_MB_PER_IMG:
             whole = ALG_MB_PER_IMG[a.model] * 1e6 * a.batch / (ms * 1e-3) / 1e9
             line["whole_path"] = {"bound": "hbm", "alg_MB_per_image": ALG_MB_PER_IMG[a.model], "achieved": round(whole, 1),
@@ -190,6 +220,7 @@ def main():
                                   "launches_per_step": plan.lib.fr_plan_num_launches(plan.handle),
                                   "sum_layer_ms": round(sum(ms_layer), 4)}
         line["kernel_families"] = {k: {"ms": round(v[0], 4), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0,
+                                        "TFLOPs": round(v[3] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0,
                                         "launches": v[2]} for k, v in fam.items()}
         if a.layers:
             for (name, kern, _, _), t, b in zip(rows, ms_layer, alg):

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvArgs a) {
     // bank swizzle of row r: the 16 rows of a ds_read_b128 lane group must hit 16 distinct 16-B slots
     auto swz = [](int row) { return BK == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int p = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const long m0 = (long)blockIdx.x * BM;
@@ -219,17 +219,19 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvArgs a) {
     for (int j = 0; j < GB; ++j) {
         const int row = RG * (wave + 4 * j) + sub;
         const int lc = pc ^ swz(row);
-        const long pix = m0 + row;
-        const bool ok = pix < a.M;
-        int sn = 0, soy = 0, sox = 0;
-        if (ok) { const int hw = a.Ho * a.Wo; sn = (int)(pix / hw); const int r = (int)(pix - (long)sn * hw); soy = r / a.Wo; sox = r - soy * a.Wo; }
+        // the launcher guarantees M + 128 < 2^31: 32-bit unsigned divisions, no 64-bit ones
+        const unsigned pix = (unsigned)m0 + (unsigned)row;
+        const bool ok = pix < (unsigned)a.M;
+        unsigned sn = 0, soy = 0, sox = 0;
+        if (ok) { const unsigned hw = (unsigned)(a.Ho * a.Wo); sn = pix / hw; const unsigned r = pix - sn * hw; soy = r / (unsigned)a.Wo; sox = r - soy * (unsigned)a.Wo; }
         xc[j] = reinterpret_cast<const unsigned char*>(
-            X + (((long)sn * a.H + (long)soy * a.stride) * a.W + (long)sox * a.stride) * a.Cin) + lc * 16;
-        unsigned mask = 0;
-        for (int t = 0; t < a.ksize * a.ksize; ++t) {
-            const int ky = t / a.ksize, kx = t - ky * a.ksize;
-            const int iy = soy * a.stride + ky - a.pad, ix = sox * a.stride + kx - a.pad;
-            if (ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) mask |= 1u << t;
+            X + (((long)sn * a.H + (long)(soy * a.stride)) * a.W + (long)(sox * a.stride)) * a.Cin) + lc * 16;
+        const int iy0 = (int)soy * a.stride - a.pad, ix0 = (int)sox * a.stride - a.pad;
+        unsigned mask = 0, bit = 1;
+        for (int ky = 0; ky < a.ksize; ++ky) {
+            const bool yok = ok && (unsigned)(iy0 + ky) < (unsigned)a.H;
+            for (int kx = 0; kx < a.ksize; ++kx, bit <<= 1)
+                if (yok && (unsigned)(ix0 + kx) < (unsigned)a.W) mask |= bit;
         }
         tapmask[j] = mask;
     }
@@ -341,7 +343,7 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
 int launch_conv(bool in_f32, bool out_f32, const ConvArgs& a, hipStream_t st) {
     if (a.Cin % 32 || a.Cin % a.bk || (a.bk != 32 && a.bk != 64) || (in_f32 && a.bk != 32) || a.e.cout % 8 || a.M <= 0 || (a.ksize != 1 && a.ksize != 3))
         FR_FAIL(FR_ERR_ARG, "conv: Cin must be a multiple of 32, Cout of 8, ksize 1 or 3");
-    if ((a.M + 127) / 128 > 0x7FFFFFFFL) FR_FAIL(FR_ERR_ARG, "conv: grid too large");
+    if (a.M + 128 >= 0x7FFFFFFFL) FR_FAIL(FR_ERR_ARG, "conv: more than 2^31 output pixels");
     if (in_f32 && out_f32) return launch_conv_t<float, float>(a, st);
     if (!in_f32 && !out_f32) return launch_conv_t<bf16, bf16>(a, st);
     if (!in_f32 && out_f32) return launch_conv_t<bf16, float>(a, st);
