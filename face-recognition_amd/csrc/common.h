@@ -138,6 +138,34 @@ FR_DEV bf16x8 to_frag(const Vec8f& x) {
 // channels per lane, i.e. wide NHWC stores.
 static inline int mfma_row_to_cout(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
 
+// ---- coalesced output through a wave-private LDS tile -------------------------------------------
+// The MFMA epilogue leaves each lane with 16 channels (32 B) of ONE pixel and its neighbour lane with
+// another pixel, so a direct store instruction writes isolated 16-byte pieces; measured on MI355X
+// that pattern tops out at 3.2-3.6 TB/s where line-contiguous stores reach 5.4 TB/s
+// (tools/micro/storepat.hip, storepat2.hip; trading halves between lanes with DPP so that lane pairs
+// write 32 B recovered only a third of the gap).  The bf16 kernels therefore put a
+// [32 pixels][<= 64 channels] tile into LDS and write it back as contiguous 16-byte chunks.
+__host__ __device__ constexpr int stage_pitch(int row_bytes) { return ((row_bytes + 127) & ~127) + 16; }   // conflict-free b128 rows
+FR_DEV void stage_put(unsigned char* stage, int pitch, int row, int col, const Vec8f& v) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = pack2bf(v.v[2 * i], v.v[2 * i + 1]);
+    *reinterpret_cast<u32x4*>(stage + row * pitch + col * 2) = r;
+}
+// Write rows [0,rows) x ncol channels of the staged tile to y (row stride ystride elements).
+FR_DEV void stage_flush(const unsigned char* stage, int pitch, int lane, bf16* y, long ystride, int ncol, int rows) {
+    const int cr = ncol >> 3;                                   // 16-byte chunks per row (<= 16)
+    const unsigned magic = (65536u + cr - 1) / cr;              // c / cr for c < 2048
+    const int total = rows * cr;
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < total; c += 64) {
+        const int row = (int)(((unsigned)c * magic) >> 16), ch = c - row * cr;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * pitch + ch * 16);
+        *reinterpret_cast<u32x4*>(y + row * ystride + ch * 8) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Common epilogue arguments of the GEMM-shaped conv kernels.
 struct EpiArgs {
     const float* bias;      // [cout_pad32] folded bias (zeros when absent)
@@ -179,5 +207,39 @@ FR_DEV void epilogue_store(const f32x16& acc, const EpiArgs& e, long m, int c0, 
             for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
         }
         store8(reinterpret_cast<TOut*>(e.y) + off, v);
+    }
+}
+
+// Same arithmetic as epilogue_store, but the bf16 result goes to the wave's LDS staging tile
+// (row = pixel within the tile, col = channel within the staged group) instead of global memory.
+FR_DEV void epilogue_stage(const f32x16& acc, const EpiArgs& e, long m, int c0, bool m_ok,
+                           unsigned char* stage, int pitch, int row, int col0) {
+    if (!m_ok) return;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        int c = c0 + 8 * g;
+        if (c >= e.cout) continue;
+        Vec8f v;
+        f32x4 b0 = *reinterpret_cast<const f32x4*>(e.bias + c);
+        f32x4 b1 = *reinterpret_cast<const f32x4*>(e.bias + c + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v.v[i] = acc[8 * g + i] + b0[i]; v.v[4 + i] = acc[8 * g + 4 + i] + b1[i]; }
+        if (e.act == FR_ACT_PRELU) {
+            f32x4 s0 = *reinterpret_cast<const f32x4*>(e.slope + c);
+            f32x4 s1 = *reinterpret_cast<const f32x4*>(e.slope + c + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v.v[i] = v.v[i] >= 0.f ? v.v[i] : v.v[i] * s0[i];
+                v.v[4 + i] = v.v[4 + i] >= 0.f ? v.v[4 + i] : v.v[4 + i] * s1[i];
+            }
+        } else if (e.act != FR_ACT_NONE) {
+            act8(v, e.act, nullptr);
+        }
+        if (e.residual) {
+            Vec8f r = load8(reinterpret_cast<const bf16*>(e.residual) + m * (long)e.cout + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
+        }
+        stage_put(stage, pitch, row, col0 + 8 * g, v);
     }
 }

@@ -15,6 +15,10 @@
 // are staged into LDS once per block when they fit (k-chunked otherwise).
 #include "kernels.h"
 
+// Kernels that may need more than the default 64 KB of dynamic LDS raise their limit first.
+#define FR_BIG_LDS(kernel, bytes) \
+    do { if ((bytes) > 65536) FR_HIP_CHECK(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); } while (0)
+
 template <typename TIn>
 struct XFrag;
 template <>
@@ -121,9 +125,27 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
                 }
             }
         }
+        if constexpr (std::is_same<TOut, bf16>::value) {
+            constexpr int SG = NTB < 2 ? NTB : 2;                 // n-tiles staged together: 128-byte rows
+            constexpr int PITCH = stage_pitch(SG * 64);
+            unsigned char* stage = smem + a.stage_off + (size_t)wave * 32 * PITCH;
+            const long tile0 = m - p, left = a.M - tile0;
 #pragma unroll
-        for (int t = 0; t < NTB; ++t)
-            if (t < nt) epilogue_store<TOut>(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok);
+            for (int tg = 0; tg < NTB; tg += SG) {
+                if (tg < nt) {
+#pragma unroll
+                    for (int t = tg; t < tg + SG; ++t)
+                        if (t < nt) epilogue_stage(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok, stage, PITCH, p, 32 * (t - tg) + 16 * h);
+                    if (left > 0)
+                        stage_flush(stage, PITCH, lane, reinterpret_cast<bf16*>(a.e.y) + tile0 * a.e.cout + (t0 + tg) * 32, a.e.cout,
+                                    min(SG * 32, a.e.cout - (t0 + tg) * 32), left < 32 ? (int)left : 32);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NTB; ++t)
+                if (t < nt) epilogue_store<TOut>(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok);
+        }
     }
 }
 
@@ -159,6 +181,10 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a) {
     const long per_iter = 128L * MT;
     const long n_iter = (a.M + per_iter - 1) / per_iter;
     const int cout = a.e.cout;
+    constexpr bool STAGED = std::is_same<TOut, bf16>::value;
+    constexpr int SG = NTB < 2 ? NTB : 2;                         // n-tiles staged together: 128-byte rows
+    constexpr int PITCH = stage_pitch(SG * 64);
+    unsigned char* stage = smem + (size_t)NTB * KS * 1024 + (size_t)NTB * 256 + (size_t)wave * 32 * PITCH;
 
     for (long it = blockIdx.x; it < n_iter; it += gridDim.x) {
         const long mbase = it * per_iter + (long)wave * 32 * MT + p;
@@ -217,8 +243,19 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a) {
 #pragma unroll
                                     for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
                                 }
-                                store8(Y + off, v);
+                                if constexpr (STAGED) stage_put(stage, PITCH, p, cl - (t / SG) * SG * 32, v);
+                                else store8(Y + off, v);
                             }
+                        }
+                    }
+                    if constexpr (STAGED) {
+                        if ((t % SG) == SG - 1 || t == nt - 1) {               // group complete: write it out
+                            const int tg = (t / SG) * SG;
+                            const long tile0 = m - p;                          // first pixel of this wave's tile
+                            const long left = a.M - tile0;
+                            if (left > 0)
+                                stage_flush(stage, PITCH, lane, reinterpret_cast<bf16*>(Y) + tile0 * cout + (t0 + tg) * 32, cout,
+                                            min(SG * 32, cout - (t0 + tg) * 32), left < 32 ? (int)left : 32);
                         }
                     }
                 }
@@ -245,10 +282,11 @@ static int launch_pw_stream(const PwArgs& a, hipStream_t st) {
     const long per_iter = 128L * mt;
     const long n_iter = (a.M + per_iter - 1) / per_iter;
     dim3 grid((unsigned)std::min<long>(n_iter, 2048), (unsigned)cdiv(a.NT, NTB));
-    const size_t lds = (size_t)NTB * a.KS * 1024 + (size_t)NTB * 256;
-    if (mt == 4) hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 4>), grid, dim3(256), lds, st, a);
-    else if (mt == 2) hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 2>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 1>), grid, dim3(256), lds, st, a);
+    size_t lds = (size_t)NTB * a.KS * 1024 + (size_t)NTB * 256;
+    if (std::is_same<TOut, bf16>::value) lds += 4 * 32 * (size_t)stage_pitch((NTB < 2 ? NTB : 2) * 64);
+    if (mt == 4) { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, 4>), lds); hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 4>), grid, dim3(256), lds, st, a); }
+    else if (mt == 2) { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, 2>), lds); hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 2>), grid, dim3(256), lds, st, a); }
+    else { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, 1>), lds); hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 1>), grid, dim3(256), lds, st, a); }
     FR_LAUNCH_CHECK("pw_stream_kernel");
     return FR_OK;
 }
@@ -268,12 +306,14 @@ static int launch_pw_t(const PwArgs& a, int ntb, hipStream_t st) {
     constexpr int NS = std::is_same<TIn, float>::value ? 2 : 1;
     const long n_super = (a.M + 127) / 128;
     dim3 grid((unsigned)std::min<long>(n_super, 2048), (unsigned)cdiv(a.NT, ntb));
-    const size_t lds = (size_t)std::min(ntb, a.NT) * a.chunk_ks * NS * 1024;
+    size_t lds = (size_t)std::min(ntb, a.NT) * a.chunk_ks * NS * 1024;
+    PwArgs b = a;
+    b.stage_off = (int)lds;
+    if (std::is_same<TOut, bf16>::value) lds += 4 * 32 * (size_t)stage_pitch(std::min(ntb, 2) * 64);
     switch (ntb) {
-        case 1: hipLaunchKernelGGL((pw_gemm_kernel<TIn, TOut, 1>), grid, dim3(256), lds, st, a); break;
-        case 2: hipLaunchKernelGGL((pw_gemm_kernel<TIn, TOut, 2>), grid, dim3(256), lds, st, a); break;
-        case 4: hipLaunchKernelGGL((pw_gemm_kernel<TIn, TOut, 4>), grid, dim3(256), lds, st, a); break;
-        case 8: hipLaunchKernelGGL((pw_gemm_kernel<TIn, TOut, 8>), grid, dim3(256), lds, st, a); break;
+        case 1: FR_BIG_LDS((pw_gemm_kernel<TIn, TOut, 1>), lds); hipLaunchKernelGGL((pw_gemm_kernel<TIn, TOut, 1>), grid, dim3(256), lds, st, b); break;
+        case 2: FR_BIG_LDS((pw_gemm_kernel<TIn, TOut, 2>), lds); hipLaunchKernelGGL((pw_gemm_kernel<TIn, TOut, 2>), grid, dim3(256), lds, st, b); break;
+        case 4: FR_BIG_LDS((pw_gemm_kernel<TIn, TOut, 4>), lds); hipLaunchKernelGGL((pw_gemm_kernel<TIn, TOut, 4>), grid, dim3(256), lds, st, b); break;
         default: FR_FAIL(FR_ERR_ARG, "pw: bad n-tile blocking");
     }
     FR_LAUNCH_CHECK("pw_gemm_kernel");

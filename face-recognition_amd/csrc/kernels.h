@@ -11,6 +11,7 @@ struct PwArgs {
     long M;
     int K, KS, NT, HW;
     int chunk_ks;         // k-steps of W staged in LDS at a time
+    int stage_off;        // set by the launcher: LDS offset of the output staging tiles
 };
 int launch_pw(bool in_f32, bool out_f32, const PwArgs& a, hipStream_t st);
 // LDS bytes per (n-tile, k-step) = 1024 * NS; used by the planner to pick chunk_ks.
