@@ -27,6 +27,7 @@ struct DwArgs {
     int N, H, W, C, Ho, Wo, pad, act;
     int TH, TW, CBV;      // output tile (TW multiple of 4) and channel-vectors (8 ch) per block
     int tiles_x, tiles_y, cchunks;
+    const void* zeros;    // >= 16 B of device zeros: LDS-DMA source for out-of-image taps and absent slopes
 };
 int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st);
 

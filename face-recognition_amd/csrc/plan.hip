@@ -482,6 +482,7 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
                 DwArgs a{};
                 a.x = xin; a.w = L.w_f32; a.bias = L.bias; a.slope = L.slope; a.y = y;
                 a.N = N; a.H = L.inH; a.W = L.inW; a.C = L.C; a.Ho = L.H; a.Wo = L.W; a.pad = L.pad; a.act = L.act;
+                a.zeros = plan->zeros;
                 if (L.fuse_src >= 0) {
                     const Layer& E = plan->layers[L.fuse_src];
                     XdwArgs xa{};
