@@ -19,6 +19,9 @@
 #define FR_BIG_LDS(kernel, bytes) \
     do { if ((bytes) > 65536) FR_HIP_CHECK(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); } while (0)
 
+typedef __attribute__((address_space(3))) void* pw_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* pw_glb_ptr_t;
+
 template <typename TIn>
 struct XFrag;
 template <>
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int p = lane & 31, h = lane >> 5;
     const int t0 = blockIdx.y * NTB;
     const int nt = min(NTB, a.NT - t0);
@@ -84,15 +88,16 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
             const int ns = min(a.chunk_ks, a.KS - s0);
             if (nchunks > 1 || !staged) {
                 if (nchunks > 1) __syncthreads();
-                const int total = nt * ns * NS * 64;          // 16-byte units
-                for (int i = threadIdx.x; i < total; i += 256) {
-                    const int unit = i & 63, f = i >> 6;
+                // LDS-DMA: one 1-KiB fragment per wave instruction, all issued before the single wait
+                const int nfrag = nt * ns * NS;
+                for (int f = wave_u; f < nfrag; f += 4) {
                     const int sp = f % NS, ts = f / NS;
                     const int s = ts % ns, t = ts / ns;
                     const u32x4* src = reinterpret_cast<const u32x4*>(a.w) +
-                        ((((long)(t0 + t) * a.KS + s0 + s) * NS + sp) * 64 + unit);
-                    reinterpret_cast<u32x4*>(smem)[i] = *src;
+                        ((((long)(t0 + t) * a.KS + s0 + s) * NS + sp) * 64 + lane);
+                    __builtin_amdgcn_global_load_lds((pw_glb_ptr_t)src, (pw_lds_ptr_t)(smem + f * 1024), 16, 0, 0);
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 staged = true;
             }
@@ -166,13 +171,16 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a) {
     bf16x8* wl = reinterpret_cast<bf16x8*>(smem);                         // [nt][KS][64]
     float* bl = reinterpret_cast<float*>(smem + (size_t)NTB * KS * 1024);  // [NTB*32] bias, then slope
     {
-        const int total = nt * KS * 64;
+        // LDS-DMA: weights as 1-KiB fragments, bias and slopes as 16-byte units; one wait for all
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         const u32x4* src = reinterpret_cast<const u32x4*>(a.w) + (size_t)t0 * KS * 64;
-        for (int i = threadIdx.x; i < total; i += 256) reinterpret_cast<u32x4*>(smem)[i] = src[i];
-        for (int i = threadIdx.x; i < nt * 32; i += 256) {
-            bl[i] = a.e.bias[t0 * 32 + i];
-            bl[NTB * 32 + i] = a.e.slope ? a.e.slope[t0 * 32 + i] : 0.f;
-        }
+        for (int f = wave_u; f < nt * KS; f += 4)
+            __builtin_amdgcn_global_load_lds((pw_glb_ptr_t)(src + f * 64 + lane), (pw_lds_ptr_t)(smem + f * 1024), 16, 0, 0);
+        if (wave_u == 0 && lane < nt * 8)
+            __builtin_amdgcn_global_load_lds((pw_glb_ptr_t)(a.e.bias + t0 * 32 + lane * 4), (pw_lds_ptr_t)(bl), 16, 0, 0);
+        if (wave_u == 1 && lane < nt * 8 && a.e.slope)
+            __builtin_amdgcn_global_load_lds((pw_glb_ptr_t)(a.e.slope + t0 * 32 + lane * 4), (pw_lds_ptr_t)(bl + NTB * 32), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     const bf16* X = reinterpret_cast<const bf16*>(a.x);
