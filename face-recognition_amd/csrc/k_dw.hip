@@ -2,82 +2,160 @@
 // PReLU / Hardswish.  Replaces nn.Conv2d(groups=C)+BatchNorm2d+activation (utils/layers.py:15-84
 // as used at :143-149, models/mobilenetv2.py:36-43, models/mobilenetv3.py:70-80).
 //
-// HBM-bound: a block stages a (TH*S+K-S) x (TW*S+K-S) x (8*CBV channel) input tile into LDS with
-// coalesced 16-byte loads (zero-filled outside the image), then every thread produces strips of
-// 4 horizontally adjacent outputs for one 8-channel vector, re-using each LDS read for up to K/S
-// outputs.  fp32 accumulate, fp32 weights (tap-major [K*K][C], BN folded in), one rounding at the store.
+// A block stages a (TH*S+K-S) x (TW*S+K-S) x (8*CBV channel) input tile into LDS by LDS-DMA
+// (global_load_lds, 16 B per lane; out-of-image taps read a zero page), then every thread produces
+// strips of horizontally adjacent outputs for one 8-channel vector, re-using each LDS read for up
+// to K/S outputs.  fp32 accumulate, fp32 weights (tap-major [K*K][C], BN folded in), one rounding at
+// the store.
+//
+// What bounds it (rocprofv3 PMC, profiles/): HBM in principle, but with 4-6 waves
+// per SIMD the VALU is 80-100 % busy, and more than half of the issued instructions used to be
+// per-thread set-up (64-bit index divisions, 64-bit address arithmetic) rather than the taps.  The
+// kernel therefore gets its divisors as host-computed 32-bit reciprocals, keeps image bases in
+// scalar registers with 32-bit per-lane offsets, and puts (image, tile row) in blockIdx.z/.y.
 #include "dw_core.h"
+#include <cstdio>
+#include <cstdlib>
 
 typedef __attribute__((address_space(3))) void* dw_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* dw_glb_ptr_t;
 
-// Staging is LDS-DMA (global_load_lds, 16 B per lane): every lane of the block issues all its
-// copies back to back and the block waits ONCE, so a tile costs one HBM round trip instead of one
-// per loop iteration (the register-staged loop compiled to load -> wait -> ds_write per iteration).
-// The DMA writes lane after lane, which is exactly the [pixel][channel-vector] order of the tile;
-// out-of-image taps read a zero page.
-template <typename T, int K, int S>
-__global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int b = blockIdx.x;
-    const int cc = b % a.cchunks; b /= a.cchunks;
-    const int tx = b % a.tiles_x; b /= a.tiles_x;
-    const int ty = b % a.tiles_y; b /= a.tiles_y;
-    const int n = b;
-    const int CV = a.C >> 3;
-    const int cv0 = cc * a.CBV;
-    const int ncv = min(a.CBV, CV - cv0);
-    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
-    const int IH = (a.TH - 1) * S + K, IW = (a.TW - 1) * S + K;
+// n / d for n * d < 2^32 with mul = floor(2^32 / d) + 1 computed on the host (d = 1: mul unused).
+struct Div32 { unsigned mul, d; };
+static inline Div32 make_div32(unsigned d) { Div32 r; r.d = d; r.mul = d > 1 ? (unsigned)((1ull << 32) / d + 1ull) : 0u; return r; }
+FR_DEV unsigned div32(unsigned n, Div32 v) { return v.d == 1 ? n : __umulhi(n, v.mul); }
 
-    constexpr int UPE = sizeof(V8<T>) / 16;                             // 16-byte units per 8-channel vector
-    V8<T>* tile = reinterpret_cast<V8<T>*>(smem);                       // [IH*IW][ncv]
-    unsigned char* wl_b = smem + (size_t)IH * IW * a.CBV * sizeof(V8<T>);
-    float* wl = reinterpret_cast<float*>(wl_b);                         // [K*K][2][ncv][4]
-    float* bl = wl + K * K * a.CBV * 8;                                 // [2][ncv][4] bias, then slope
-    const unsigned char* X = reinterpret_cast<const unsigned char*>(a.x);
+struct DwGeom {          // derived launch geometry (host computed)
+    Div32 d_cbv, d_iw, d_ns;
+    int IH, IW, nstrips, nitems, nunits;
+    int n0;              // first image of this launch slice (blockIdx.z is relative to it)
+};
+
+template <int S> __host__ __device__ constexpr int dw_sw() { return S == 2 ? 2 : 4; }
+
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int SW = dw_sw<S>();                  // outputs per work item (see dw_pick_tile)
+    constexpr int IWS = (SW - 1) * S + K;
+    constexpr int UPE = sizeof(V8<T>) / 16;         // 16-byte units per 8-channel vector
+    const int CBV = a.CBV, CV = a.C >> 3;
+    const int cc = blockIdx.x % a.cchunks, tx = blockIdx.x / a.cchunks, ty = blockIdx.y;
+    const int n = g.n0 + blockIdx.z;
+    const int cv0 = cc * CBV, ncv = min(CBV, CV - cv0);
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int IW = g.IW;
+
+    const V8<T>* tile = reinterpret_cast<const V8<T>*>(smem);            // [IH*IW][CBV]
+    unsigned char* wl_b = smem + (size_t)g.IH * IW * CBV * sizeof(V8<T>);
+    const float* wl = reinterpret_cast<const float*>(wl_b);              // [K*K][2][CBV][4]
+    const float* bl = wl + K * K * CBV * 8;                              // [2][CBV][4] bias, then slopes
+    const unsigned char* Xn = reinterpret_cast<const unsigned char*>(a.x) + (size_t)n * a.H * a.W * a.C * sizeof(T);
+    unsigned char* Yn = reinterpret_cast<unsigned char*>(a.y) + (size_t)n * a.Ho * a.Wo * a.C * sizeof(T);
     const unsigned char* Z = reinterpret_cast<const unsigned char*>(a.zeros);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;
-    const int nunits = IH * IW * ncv * UPE;
-    const FastDiv d_ncv(ncv), d_iw(IW);
-    for (int u0 = wave * 64; u0 < nunits; u0 += 256) {
+    // ---- stage: input tile
+    for (int u0 = wave * 64; u0 < g.nunits; u0 += 256) {
         const int u = u0 + lane;
-        if (u < nunits) {
-            unsigned cv, pix, iy, ix;
-            d_ncv.divmod((unsigned)u / UPE, pix, cv);
-            d_iw.divmod(pix, iy, ix);
+        if (u < g.nunits) {
+            const unsigned q = (unsigned)u / UPE;
+            const unsigned pix = div32(q, g.d_cbv), cv = q - pix * CBV;
+            const unsigned iy = div32(pix, g.d_iw), ix = pix - iy * IW;
             const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
-            const unsigned char* src = Z;
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                src = X + ((((long)n * a.H + gy) * a.W + gx) * a.C + (cv0 + cv) * 8) * sizeof(T) + (u % UPE) * 16;
+            const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && (int)cv < ncv;
+            const int off = ((gy * a.W + gx) * a.C + (cv0 + (int)cv) * 8) * (int)sizeof(T) + (u % UPE) * 16;
+            const unsigned char* src = ok ? Xn + off : Z;
             __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + u0 * 16), 16, 0, 0);
         }
     }
-    // tap weights: unit (tap, half, cv) = 4 floats w[tap][(cv0+cv)*8 + 4*half ..]
-    const int nw = K * K * 2 * ncv;
+    // ---- stage: tap weights, unit (tap, half, cv) = 4 floats w[tap][(cv0+cv)*8 + 4*half ..]
+    const int nw = K * K * 2 * CBV;
     for (int u0 = wave * 64; u0 < nw; u0 += 256) {
         const int u = u0 + lane;
         if (u < nw) {
-            unsigned r, cv;
-            d_ncv.divmod(u, r, cv);
-            const float* src = a.w + (long)(r >> 1) * a.C + (cv0 + cv) * 8 + (r & 1) * 4;
+            const unsigned r = div32(u, g.d_cbv), cv = u - r * CBV;
+            const void* src = (int)cv < ncv ? (const void*)(a.w + (r >> 1) * a.C + (cv0 + cv) * 8 + (r & 1) * 4) : (const void*)Z;
             __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(wl_b + u0 * 16), 16, 0, 0);
         }
     }
-    // bias [2][ncv][4], then slopes [2][ncv][4]
-    const int nb = 2 * ncv;
-    if (wave == 0 && lane < 2 * nb) {                                   // 2*nb <= 64 is checked by the launcher
+    // ---- stage: bias [2][CBV][4], then slopes [2][CBV][4]   (4*CBV <= 64 lanes)
+    if (wave == 0 && lane < 4 * CBV) {
+        const int nb = 2 * CBV;
         const int which = lane >= nb, r = lane - which * nb;
-        const int half = r / ncv, cv = r - half * ncv;
-        const float* base = which ? a.slope : a.bias;
-        const void* src = base ? (const void*)(base + (cv0 + cv) * 8 + half * 4) : (const void*)Z;
-        __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(reinterpret_cast<unsigned char*>(bl)), 16, 0, 0);
+        const int half = r >= CBV, cv = r - half * CBV;
+        const float* pb = which ? a.slope : a.bias;
+        const void* src = (pb && cv < ncv) ? (const void*)(pb + (cv0 + cv) * 8 + half * 4) : (const void*)Z;
+        __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(wl_b + K * K * CBV * 32), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    dw_compute<T, K, S>(a, tile, wl, bl, n, oy0, ox0, cv0, ncv, IW);
+
+    // ---- compute
+    for (int it = threadIdx.x; it < g.nitems; it += 256) {
+        const unsigned r = div32(it, g.d_cbv), cv = it - r * CBV;
+        const unsigned oy = div32(r, g.d_ns), sx = r - oy * g.nstrips;
+        if ((int)cv >= ncv) continue;
+        float acc[SW][8];
+        {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl + (0 * CBV + cv) * 4);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bl + (1 * CBV + cv) * 4);
+#pragma unroll
+            for (int o = 0; o < SW; ++o)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[o][j] = b0[j]; acc[o][4 + j] = b1[j]; }
+        }
+        const V8<T>* row = tile + ((oy * S) * IW + sx * SW * S) * CBV + cv;
+        const float* wrow = wl + cv * 4;
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+            float wr[K][8];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow + (kx * 2 + 0) * CBV * 4);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wrow + (kx * 2 + 1) * CBV * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { wr[kx][j] = w0[j]; wr[kx][4 + j] = w1[j]; }
+            }
+#pragma unroll
+            for (int ix = 0; ix < IWS; ++ix) {
+                const Vec8f v = load8(reinterpret_cast<const T*>(row + ix * CBV));
+#pragma unroll
+                for (int o = 0; o < SW; ++o) {
+                    const int kx = ix - o * S;
+                    if (kx >= 0 && kx < K) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[o][j] = fmaf(v.v[j], wr[kx][j], acc[o][j]);
+                    }
+                }
+            }
+            row += IW * CBV;
+            wrow += K * 2 * CBV * 4;
+        }
+        const int gy = oy0 + (int)oy;
+        if (gy < a.Ho) {
+            float sl[8];
+            if (a.act == FR_ACT_PRELU) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(bl + CBV * 8 + (0 * CBV + cv) * 4);
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(bl + CBV * 8 + (1 * CBV + cv) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sl[j] = s0[j]; sl[4 + j] = s1[j]; }
+            }
+            const int gx0o = ox0 + (int)sx * SW;
+            const int yoff = ((gy * a.Wo + gx0o) * a.C + (cv0 + (int)cv) * 8) * (int)sizeof(T);
+#pragma unroll
+            for (int o = 0; o < SW; ++o) {
+                if (gx0o + o < a.Wo) {
+                    Vec8f v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v.v[j] = acc[o][j];
+                    act8(v, a.act, sl);
+                    store8(reinterpret_cast<T*>(Yn + yoff + o * a.C * (int)sizeof(T)), v);
+                }
+            }
+        }
+    }
 }
 
 static size_t dw_lds_bytes(bool f32, int k, int s, int TH, int TW, int CBV) {
@@ -87,8 +165,12 @@ static size_t dw_lds_bytes(bool f32, int k, int s, int TH, int TW, int CBV) {
 
 // Pick the output tile and channel chunk: keep LDS <= 40 KB (>= 3 blocks per CU), prefer all
 // channels in one block (long contiguous NHWC runs), then the least padded-work + halo overhead.
+// Work items are strips of 4 outputs at stride 1 (each LDS read serves up to K outputs) and of 2 at
+// stride 2 (2+K columns for 2 outputs is within 10 % of a strip of 4, and the LDS-limited stride-2
+// tiles get twice the work items).
 static void dw_pick_tile(bool f32, int k, int s, DwArgs& a) {
     const int CV = a.C / 8;
+    const int sw = s == 2 ? 2 : 4;
     double best = 1e30;
     const int ths[] = {2, 4, 7, 8, 14, 16};
     const int tws[] = {4, 8, 12, 16, 28, 32, 56};
@@ -98,7 +180,7 @@ static void dw_pick_tile(bool f32, int k, int s, DwArgs& a) {
         for (int cbv = std::min(CV, 16); cbv >= 1; cbv = (cbv > 1 ? (cbv + 1) / 2 : 0)) {
             if (dw_lds_bytes(f32, k, s, th, tw, cbv) > 40 * 1024) continue;
             const int tyc = cdiv(a.Ho, th), txc = cdiv(a.Wo, tw), ccs = cdiv(CV, cbv);
-            const int items = th * (tw / 4) * cbv;
+            const int items = th * (tw / sw) * cbv;
             const double passes = cdiv(items, 256);
             const double IH = (th - 1) * s + k, IW = (tw - 1) * s + k;
             // cost ~ compute passes + staged input vectors / 256 (load loop), per useful output
@@ -111,24 +193,45 @@ static void dw_pick_tile(bool f32, int k, int s, DwArgs& a) {
 }
 
 template <typename T>
-static int launch_dw_t(int k, int s, const DwArgs& a, size_t lds, hipStream_t st) {
-    dim3 grid((unsigned)((long)a.N * a.tiles_y * a.tiles_x * a.cchunks));
-#define FR_DW_CASE(KK, SS) if (k == KK && s == SS) { hipLaunchKernelGGL((dw_kernel<T, KK, SS>), grid, dim3(256), lds, st, a); }
-    FR_DW_CASE(3, 1) else FR_DW_CASE(3, 2) else FR_DW_CASE(5, 1) else FR_DW_CASE(5, 2)
-    else FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: only k in {3,5}, stride in {1,2}");
+static int launch_dw_t(int k, int s, const DwArgs& a, DwGeom g, size_t lds, hipStream_t st) {
+    for (int n0 = 0; n0 < a.N; n0 += 65535) {          // blockIdx.z carries the image
+        g.n0 = n0;
+        dim3 grid((unsigned)(a.tiles_x * a.cchunks), (unsigned)a.tiles_y, (unsigned)std::min(65535, a.N - n0));
+#define FR_DW_CASE(KK, SS) if (k == KK && s == SS) { hipLaunchKernelGGL((dw_kernel<T, KK, SS>), grid, dim3(256), lds, st, a, g); }
+        FR_DW_CASE(3, 1) else FR_DW_CASE(3, 2) else FR_DW_CASE(5, 1) else FR_DW_CASE(5, 2)
+        else FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: only k in {3,5}, stride in {1,2}");
 #undef FR_DW_CASE
-    FR_LAUNCH_CHECK("dw_kernel");
+        FR_LAUNCH_CHECK("dw_kernel");
+    }
     return FR_OK;
 }
 
 int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st) {
     if (a.C % 8 || a.N <= 0) FR_FAIL(FR_ERR_ARG, "depthwise: C must be a multiple of 8");
     if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: only k in {3,5}, stride in {1,2}");
+    if (!a.zeros) FR_FAIL(FR_ERR_ARG, "depthwise: no zero page");
+    if ((long)a.H * a.W * a.C * 4 >= 0x7FFFFFFFL) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: image above 2 GB");
     a.TH = 0;
     dw_pick_tile(f32, k, stride, a);
     if (a.TH == 0) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: no tile fits LDS");
-    if (a.CBV > 16 || !a.zeros) FR_FAIL(FR_ERR_ARG, "depthwise: channel chunk above 128 channels or no zero page");
-    if ((long)a.N * a.tiles_y * a.tiles_x * a.cchunks > 0x7FFFFFFFL) FR_FAIL(FR_ERR_ARG, "depthwise: grid too large");
+    if (const char* ov = getenv("FR_DW_TILE")) {           // tuning override: "C,Ho,k,s,TH,TW,CBV" for the matching layers
+        int c, ho, kk, ss, th, tw, cbv;
+        if (sscanf(ov, "%d,%d,%d,%d,%d,%d,%d", &c, &ho, &kk, &ss, &th, &tw, &cbv) == 7 && c == a.C && ho == a.Ho && kk == k &&
+            ss == stride && th > 0 && tw > 0 && tw % 4 == 0 && cbv > 0 && cbv <= 16) {
+            a.TH = th; a.TW = tw; a.CBV = std::min(cbv, a.C / 8);
+            a.tiles_y = cdiv(a.Ho, th); a.tiles_x = cdiv(a.Wo, tw); a.cchunks = cdiv(a.C / 8, a.CBV);
+        }
+    }
+    if (a.CBV > 16) FR_FAIL(FR_ERR_ARG, "depthwise: channel chunk above 128 channels");
+    if (a.tiles_y > 65535 || (long)a.tiles_x * a.cchunks > 0x7FFFFFFFL) FR_FAIL(FR_ERR_ARG, "depthwise: grid too large");
     const size_t lds = dw_lds_bytes(f32, k, stride, a.TH, a.TW, a.CBV);
-    return f32 ? launch_dw_t<float>(k, stride, a, lds, st) : launch_dw_t<bf16>(k, stride, a, lds, st);
+    if (lds > 64 * 1024) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: tile above 64 KB of LDS");
+    DwGeom g{};
+    const int sw = stride == 2 ? 2 : 4;
+    g.IH = (a.TH - 1) * stride + k; g.IW = (a.TW - 1) * stride + k;
+    g.nstrips = a.TW / sw;
+    g.nitems = a.TH * g.nstrips * a.CBV;
+    g.nunits = g.IH * g.IW * a.CBV * (f32 ? 2 : 1);
+    g.d_cbv = make_div32(a.CBV); g.d_iw = make_div32(g.IW); g.d_ns = make_div32(g.nstrips);
+    return f32 ? launch_dw_t<float>(k, stride, a, g, lds, st) : launch_dw_t<bf16>(k, stride, a, g, lds, st);
 }
