@@ -272,6 +272,76 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a) {
     }
 }
 
+// ---- small-M GEMM: SE fc1/fc2 on the pooled [batch, C] vectors, the final Linear(+BN1d), the
+// SphereFace fc.  M is only the batch, so the pixel-tiled kernels above would launch a handful of
+// blocks; here one block owns a 32-row x 32-column output tile, its four waves split K, keep eight
+// k-steps of loads in flight each, and reduce through LDS.  fp32 output; fp32 input is split hi+lo.
+template <typename TIn>
+__global__ __launch_bounds__(256) void fc_kernel(PwArgs a) {
+    constexpr int NS = std::is_same<TIn, float>::value ? 2 : 1;
+    __shared__ float red[3][16][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int p = lane & 31, h = lane >> 5;
+    const long m = (long)blockIdx.x * 32 + p;
+    const bool m_ok = m < a.M;
+    const int t = blockIdx.y;
+    const int ks_per = (a.KS + 3) >> 2;
+    const int s_begin = wave * ks_per, s_end = min(a.KS, s_begin + ks_per);
+    const TIn* xrow = reinterpret_cast<const TIn*>(a.x) + (m_ok ? m : a.M - 1) * (long)a.K;
+    const bf16x8* W = reinterpret_cast<const bf16x8*>(a.w) + (size_t)t * a.KS * NS * 64 + lane;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int sg = s_begin; sg < s_end; sg += 8) {
+        XFrag<TIn> xf[8];
+        bf16x8 wf[8][NS];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = sg + j, kk = s * 16 + 8 * h;
+            if (s < s_end && kk < a.K) xf[j].load(xrow + kk, nullptr);
+            else xf[j].zero();
+            const int sc = s < s_end ? s : s_end - 1;
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) wf[j][sp] = W[((size_t)sc * NS + sp) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (sg + j < s_end) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][0], xf[j].hi, acc, 0, 0, 0);
+                if constexpr (NS == 2) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][0], xf[j].lo, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][1], xf[j].hi, acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)                       // fixed order: deterministic
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += red[w][r][lane];
+        epilogue_store<float>(acc, a.e, m, 32 * t + 16 * h, m_ok);
+    }
+}
+
+int launch_fc(bool in_f32, const PwArgs& a, hipStream_t st) {
+    if (a.M <= 0 || a.K <= 0 || a.K % 8 || a.e.cout % 8 || a.KS != cdiv(a.K, 16) || a.NT != cdiv(a.e.cout, 32) || a.se || a.e.residual)
+        FR_FAIL(FR_ERR_ARG, "fc: inconsistent shapes");
+    const long mt = (a.M + 31) / 32;
+    if (mt > 0x7FFFFFFFL || a.NT > 65535) FR_FAIL(FR_ERR_ARG, "fc: grid too large");
+    dim3 grid((unsigned)mt, (unsigned)a.NT);
+    if (in_f32) hipLaunchKernelGGL((fc_kernel<float>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((fc_kernel<bf16>), grid, dim3(256), 0, st, a);
+    FR_LAUNCH_CHECK("fc_kernel");
+    return FR_OK;
+}
+
 void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks) {
     const int ns = in_f32 ? 2 : 1;
     const int cap = 4;

@@ -14,6 +14,8 @@ struct PwArgs {
     int stage_off;        // set by the launcher: LDS offset of the output staging tiles
 };
 int launch_pw(bool in_f32, bool out_f32, const PwArgs& a, hipStream_t st);
+// Small-M form (M = batch): SE fc layers, Linear(+BN1d).  fp32 output, no SE scale, no residual.
+int launch_fc(bool in_f32, const PwArgs& a, hipStream_t st);
 // LDS bytes per (n-tile, k-step) = 1024 * NS; used by the planner to pick chunk_ks.
 void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks);
 

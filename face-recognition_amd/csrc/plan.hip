@@ -273,7 +273,7 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
                     W[(size_t)o * K + (size_t)p * s.C + c] = (double)d.weight[(size_t)o * K + (size_t)c * HW + p] * scale[o];
         std::vector<uint16_t> packed;
         int rc;
-        if (K >= 4096 && K % 32 == 0) {           // SphereFace fc: K-streaming implicit-GEMM kernel
+        if (false && K >= 4096 && K % 32 == 0) {  // (the implicit-GEMM route launched 16 blocks for the SphereFace fc; fc_kernel launches 256)
             L.via_conv = true;
             L.conv_bk = (!L.in_f32 && K % 64 == 0) ? 64 : 32;
             pack_conv_weights([&](int co, int, int c) { return W[(size_t)co * K + c]; }, d.cout, K, 1, L.in_f32 ? 2 : 1, L.conv_bk, packed);
@@ -475,7 +475,7 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
                 a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act};
                 a.M = L.kind == K_PW ? (long)N * L.H * L.W : (long)N;
                 a.K = L.K; a.KS = L.KS; a.NT = L.NT; a.HW = L.H * L.W; a.chunk_ks = L.chunk_ks;
-                rc = launch_pw(L.in_f32, L.out_f32, a, st);
+                rc = L.kind == K_LINEAR ? launch_fc(L.in_f32, a, st) : launch_pw(L.in_f32, L.out_f32, a, st);
                 break;
             }
             case K_DW: {
@@ -510,13 +510,13 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
                 a.x = pool; a.w = L.w_packed; a.se = nullptr;
                 a.e = EpiArgs{L.bias, nullptr, nullptr, hid, L.cout, FR_ACT_RELU};
                 a.M = N; a.K = L.K; a.KS = L.KS; a.NT = L.NT; a.HW = 1; a.chunk_ks = L.chunk_ks;
-                rc = launch_pw(true, true, a, st);
+                rc = launch_fc(true, a, st);
                 if (rc) break;
                 PwArgs b{};
                 b.x = hid; b.w = L.w_packed2; b.se = nullptr;
                 b.e = EpiArgs{L.bias2, nullptr, nullptr, y, L.cin, FR_ACT_HSIGMOID};
                 b.M = N; b.K = L.K2; b.KS = L.KS2; b.NT = L.NT2; b.HW = 1; b.chunk_ks = L.chunk_ks2;
-                rc = launch_pw(true, true, b, st);
+                rc = launch_fc(true, b, st);
                 break;
             }
             default: FR_FAIL(FR_ERR_UNSUPPORTED, "fr_embed: kernel kind not built");
@@ -566,8 +566,8 @@ extern "C" int fr_embed_profile(const fr_plan* plan, const float* x, int batch, 
 
 extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char** name) {
     if (!plan || layer < 0 || layer >= (int)plan->layers.size() || !name) FR_FAIL(FR_ERR_ARG, "fr_plan_layer_kernel: bad layer");
-    static const char* names[] = {"stem_kernel", "pw_gemm_kernel", "dw_kernel", "reduce_kernel", "se(reduce+2xpw_gemm)",
-                                  "pw_gemm_kernel", "conv3x3_kernel"};
+    static const char* names[] = {"stem_kernel", "pw_gemm_kernel", "dw_kernel", "reduce_kernel", "se(reduce+2xfc)",
+                                  "fc_kernel", "conv3x3_kernel"};
     *name = names[plan->layers[layer].kind];
     return FR_OK;
 }
