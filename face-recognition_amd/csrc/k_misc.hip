@@ -18,15 +18,27 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
     const T* X = reinterpret_cast<const T*>(a.x) + (long)n * a.P * a.C + (cv0 + cv) * 8;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (ps < PS) {
-        for (int p = ps; p < a.P; p += PS) {
-            Vec8f v = load8(X + (long)p * a.C);
-            if (a.w) {
-                Vec8f w = load8(a.w + (long)p * a.C + (cv0 + cv) * 8);
+        // four loads in flight per thread; the summation order (p ascending) is unchanged
+        for (int p0 = ps; p0 < a.P; p0 += 4 * PS) {
+            Vec8f v[4], w[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s[j] = fmaf(v.v[j], w.v[j], s[j]);
-            } else {
+            for (int q = 0; q < 4; ++q) {
+                const int p = p0 + q * PS;
+                const int pc = p < a.P ? p : ps;
+                v[q] = load8(X + (long)pc * a.C);
+                if (a.w) w[q] = load8(a.w + (long)pc * a.C + (cv0 + cv) * 8);
+            }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s[j] += v.v[j];
+            for (int q = 0; q < 4; ++q) {
+                if (p0 + q * PS < a.P) {
+                    if (a.w) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) s[j] = fmaf(v[q].v[j], w[q].v[j], s[j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) s[j] += v[q].v[j];
+                    }
+                }
             }
         }
     }
