@@ -159,9 +159,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
 // Each wave owns MT consecutive 32-pixel tiles per iteration and issues ALL their activation (and
 // residual) loads before the first MFMA, so that >= 2-4 KB per wave are in flight: the op is pure
 // HBM streaming and bytes in flight per CU, not arithmetic, set its speed.
-template <typename TOut, int NTB, int MT>
+template <typename TOut, int NTB, int MT, int KSM = 8 / MT>     // KSM: max k-steps
 __global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a) {
-    constexpr int KSM = 8 / MT;                     // max k-steps
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
@@ -344,7 +343,10 @@ int launch_fc(bool in_f32, const PwArgs& a, hipStream_t st) {
 
 void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks) {
     const int ns = in_f32 ? 2 : 1;
-    const int cap = 4;
+    // bf16, 128 < K <= 256: two n-tiles per block keep the whole weight slab (<= 32 KB) resident,
+    // so the streaming kernel applies (no k-chunk restaging); the activations are re-read from L2
+    // by the extra column groups.
+    const int cap = (!in_f32 && KS > 8 && KS <= 16) ? 2 : 4;
     int b = 1;
     while (b < NT && b < cap) b *= 2;
     int ck = 48 / (b * ns);           // <= 48 KB of LDS
@@ -356,15 +358,16 @@ void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks) {
 
 template <typename TOut, int NTB>
 static int launch_pw_stream(const PwArgs& a, hipStream_t st) {
-    const int mt = a.KS <= 2 ? 4 : (a.KS <= 4 ? 2 : 1);
-    const long per_iter = 128L * mt;
+    const int mt = a.KS <= 2 ? 4 : (a.KS <= 4 ? 2 : (a.KS <= 8 ? 1 : 0));
+    const long per_iter = 128L * (mt ? mt : 1);
     const long n_iter = (a.M + per_iter - 1) / per_iter;
     dim3 grid((unsigned)std::min<long>(n_iter, 2048), (unsigned)cdiv(a.NT, NTB));
     size_t lds = (size_t)NTB * a.KS * 1024 + (size_t)NTB * 256;
     if (std::is_same<TOut, bf16>::value) lds += 4 * 32 * (size_t)stage_pitch((NTB < 2 ? NTB : 2) * 64);
     if (mt == 4) { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, 4>), lds); hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 4>), grid, dim3(256), lds, st, a); }
     else if (mt == 2) { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, 2>), lds); hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 2>), grid, dim3(256), lds, st, a); }
-    else { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, 1>), lds); hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 1>), grid, dim3(256), lds, st, a); }
+    else if (mt == 1) { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, 1>), lds); hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 1>), grid, dim3(256), lds, st, a); }
+    else { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, 1, 16>), lds); hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 1, 16>), grid, dim3(256), lds, st, a); }
     FR_LAUNCH_CHECK("pw_stream_kernel");
     return FR_OK;
 }
@@ -372,7 +375,7 @@ static int launch_pw_stream(const PwArgs& a, hipStream_t st) {
 template <typename TIn, typename TOut>
 static int launch_pw_t(const PwArgs& a, int ntb, hipStream_t st) {
     if constexpr (std::is_same<TIn, bf16>::value) {
-        if (a.KS <= 8 && a.chunk_ks >= a.KS) {
+        if (a.KS <= 16 && a.chunk_ks >= a.KS && (a.KS <= 8 || ntb <= 2)) {
             switch (ntb) {
                 case 1: return launch_pw_stream<TOut, 1>(a, st);
                 case 2: return launch_pw_stream<TOut, 2>(a, st);
