@@ -155,6 +155,160 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
 }
 
 
+// ---- large-K variant (K > 256, bf16): the project convs after squeeze-excite ------------------------
+// The k-chunked kernel above stages a weight chunk, waits, computes, and only then asks for the
+// next chunk and the next activations: every chunk pays a full memory round trip.  Here a block
+// owns 128 pixels x (up to 5 n-tiles = 160 channels), and both streams are software-pipelined:
+// while chunk c (4 k-steps = 64 input channels) is multiplied, the LDS-DMA of weight chunk c+1
+// into the other LDS buffer and the loads of activation chunk c+1 (and its SE scales) into a
+// second register set are already in flight.  One wait + one barrier per chunk.
+constexpr int PJ_CK = 4;          // k-steps per chunk
+constexpr int PJ_NT = 5;          // n-tiles per block
+
+constexpr int PJ_IMGS = 4;        // images a 128-pixel super-tile can span (needs H*W >= 43)
+struct PjRaw { u32x4 x[PJ_CK]; };
+
+template <bool SE>
+__global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WBUF = PJ_NT * PJ_CK * 1024;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int p = lane & 31, h = lane >> 5;
+    const int t0 = blockIdx.y * a.ntg;
+    const int nt = min(a.ntg, a.NT - t0);
+    const int nch = (a.KS + PJ_CK - 1) / PJ_CK;
+    const long n_super = (a.M + 127) / 128;
+    const bf16* X = reinterpret_cast<const bf16*>(a.x);
+    constexpr int SG = 2;
+    constexpr int PITCH = stage_pitch(SG * 64);
+    unsigned char* stage = smem + 2 * WBUF + (size_t)wave * 32 * PITCH;
+    // SE scales of the (<= 4) images this super-tile touches: [PJ_IMGS][K] fp32, staged once per
+    // super-tile (per-lane global loads of the scales would be twice the activation bytes)
+    float* sc = reinterpret_cast<float*>(smem + 2 * WBUF + 4 * 32 * PITCH);
+    const long n_img = a.M / a.HW;
+
+    for (long st = blockIdx.x; st < n_super; st += gridDim.x) {
+        const long m = st * 128 + wave * 32 + p;
+        const bool m_ok = m < a.M;
+        const long mc = m_ok ? m : a.M - 1;
+        const bf16* xrow = X + mc * (long)a.K;
+        const long img0 = (st * 128) / a.HW;
+        const float* srow = sc + (int)(mc / a.HW - img0) * a.K;
+        if constexpr (SE) {
+            const int upr = a.K >> 2;                                   // 16-byte units per scale row
+            const int nu = PJ_IMGS * upr;
+            for (int u0 = wave * 64; u0 < nu; u0 += 256) {
+                const int u = u0 + lane;
+                if (u < nu) {
+                    const int i = u / upr, r = u - i * upr;
+                    const long img = img0 + i < n_img ? img0 + i : n_img - 1;
+                    __builtin_amdgcn_global_load_lds((pw_glb_ptr_t)(a.se + img * a.K + r * 4),
+                                                     (pw_lds_ptr_t)(reinterpret_cast<unsigned char*>(sc) + u0 * 16), 16, 0, 0);
+                }
+            }
+        }
+
+        auto issue = [&](int c, int buf, PjRaw& raw) {
+            const int s0 = c * PJ_CK;
+            const int ns = min(PJ_CK, a.KS - s0);
+            const int nfrag = nt * ns;
+            for (int f = wave; f < nfrag; f += 4) {
+                const int t = f / ns, s = f - t * ns;
+                const u32x4* src = reinterpret_cast<const u32x4*>(a.w) + (((long)(t0 + t) * a.KS + s0 + s) * 64 + lane);
+                __builtin_amdgcn_global_load_lds((pw_glb_ptr_t)src, (pw_lds_ptr_t)(smem + buf * WBUF + (t * PJ_CK + s) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < PJ_CK; ++j) {
+                const int kk = (s0 + j) * 16 + 8 * h;
+                const int kc = kk < a.K ? kk : 0;                       // clamped: the k-step is skipped or its weights are zero
+                raw.x[j] = *reinterpret_cast<const u32x4*>(xrow + kc);
+            }
+        };
+
+        f32x16 acc[PJ_NT];
+#pragma unroll
+        for (int t = 0; t < PJ_NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+        auto compute = [&](int c, int buf, const PjRaw& raw) {
+            const int s0 = c * PJ_CK;
+            const int ns = min(PJ_CK, a.KS - s0);
+            const bf16x8* wb = reinterpret_cast<const bf16x8*>(smem + buf * WBUF) + lane;
+#pragma unroll
+            for (int j = 0; j < PJ_CK; ++j) {
+                if (j < ns) {
+                    bf16x8 xf;
+                    const bool live = (s0 + j) * 16 + 8 * h < a.K;
+                    if constexpr (SE) {
+                        Vec8f x;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            x.v[2 * i] = __uint_as_float(raw.x[j][i] << 16);
+                            x.v[2 * i + 1] = __uint_as_float(raw.x[j][i] & 0xffff0000u);
+                        }
+                        const int kc = live ? (s0 + j) * 16 + 8 * h : 0;
+                        const f32x4 sa = *reinterpret_cast<const f32x4*>(srow + kc), sb = *reinterpret_cast<const f32x4*>(srow + kc + 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { x.v[i] *= sa[i]; x.v[4 + i] *= sb[i]; }
+                        xf = to_frag(x);
+                    } else {
+                        xf = __builtin_bit_cast(bf16x8, raw.x[j]);
+                    }
+                    if (!live) xf = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int t = 0; t < PJ_NT; ++t)
+                        if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[(t * PJ_CK + j) * 64], xf, acc[t], 0, 0, 0);
+                }
+            }
+        };
+
+        PjRaw r0, r1;
+        issue(0, 0, r0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int c = 0; c < nch; c += 2) {
+            if (c + 1 < nch) issue(c + 1, 1, r1);
+            compute(c, 0, r0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (c + 1 < nch) {
+                if (c + 2 < nch) issue(c + 2, 0, r0);
+                compute(c + 1, 1, r1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+
+        const long tile0 = m - p, left = a.M - tile0;
+#pragma unroll
+        for (int tg = 0; tg < PJ_NT; tg += SG) {
+            if (tg < nt) {
+#pragma unroll
+                for (int t = tg; t < tg + SG; ++t)
+                    if (t < PJ_NT && t < nt) epilogue_stage(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok, stage, PITCH, p, 32 * (t - tg) + 16 * h);
+                if (left > 0)
+                    stage_flush(stage, PITCH, lane, reinterpret_cast<bf16*>(a.e.y) + tile0 * a.e.cout + (t0 + tg) * 32, a.e.cout,
+                                min(SG * 32, min(a.e.cout, (t0 + nt) * 32) - (t0 + tg) * 32), left < 32 ? (int)left : 32);
+            }
+        }
+    }
+}
+
+static int launch_pw_proj(const PwArgs& a, hipStream_t st) {
+    const long n_super = (a.M + 127) / 128;
+    PwArgs b = a;
+    b.ntg = PJ_NT;
+    const int groups = cdiv(a.NT, b.ntg);
+    dim3 grid((unsigned)std::min<long>(n_super, 4096), (unsigned)groups);
+    size_t lds = 2 * (size_t)PJ_NT * PJ_CK * 1024 + 4 * 32 * (size_t)stage_pitch(2 * 64);
+    if (a.se) lds += (size_t)PJ_IMGS * a.K * 4;
+    if (a.se) { FR_BIG_LDS((pw_proj_kernel<true>), lds); hipLaunchKernelGGL((pw_proj_kernel<true>), grid, dim3(256), lds, st, b); }
+    else hipLaunchKernelGGL((pw_proj_kernel<false>), grid, dim3(256), lds, st, b);
+    FR_LAUNCH_CHECK("pw_proj_kernel");
+    return FR_OK;
+}
+
 // ---- streaming variant: all weights (+bias/slope) resident in LDS, K <= 128, bf16 input.
 // Each wave owns MT consecutive 32-pixel tiles per iteration and issues ALL their activation (and
 // residual) loads before the first MFMA, so that >= 2-4 KB per wave are in flight: the op is pure
@@ -408,6 +562,7 @@ int launch_pw(bool in_f32, bool out_f32, const PwArgs& a, hipStream_t st) {
     pw_pick_tiling(in_f32, a.NT, a.KS, &ntb, &ck);
     if (ck != a.chunk_ks) FR_FAIL(FR_ERR_ARG, "pw: chunk_ks does not match pw_pick_tiling");
     if (in_f32 && out_f32) return launch_pw_t<float, float>(a, ntb, st);
+    if (!in_f32 && !out_f32 && a.KS > 16 && (!a.se || (a.HW >= 43 && a.M % a.HW == 0))) return launch_pw_proj(a, st);
     if (!in_f32 && !out_f32) return launch_pw_t<bf16, bf16>(a, ntb, st);
     if (!in_f32 && out_f32) return launch_pw_t<bf16, float>(a, ntb, st);
     FR_FAIL(FR_ERR_UNSUPPORTED, "pw: fp32 input with bf16 output is not instantiated");

@@ -12,6 +12,7 @@ struct PwArgs {
     int K, KS, NT, HW;
     int chunk_ks;         // k-steps of W staged in LDS at a time
     int stage_off;        // set by the launcher: LDS offset of the output staging tiles
+    int ntg;              // set by the launcher: n-tiles per column group (large-K kernel)
 };
 int launch_pw(bool in_f32, bool out_f32, const PwArgs& a, hipStream_t st);
 // Small-M form (M = batch): SE fc layers, Linear(+BN1d).  fp32 output, no SE scale, no residual.
