@@ -555,6 +555,17 @@ static int launch_pw_t(const PwArgs& a, int ntb, hipStream_t st) {
     return FR_OK;
 }
 
+// Which kernel launch_pw picks for a layer shape (diagnostics: fr_plan_layer_kernel, bench.py).
+const char* pw_kernel_name(bool in_f32, bool out_f32, int K, int cout, bool se, int HW) {
+    const int KS = cdiv(K, 16), NT = cdiv(cout, 32);
+    int ntb, ck;
+    pw_pick_tiling(in_f32, NT, KS, &ntb, &ck);
+    if (in_f32) return "pw_gemm_kernel";
+    if (!out_f32 && KS > 16 && (!se || HW >= 43)) return "pw_proj_kernel";
+    if (KS <= 16 && ck >= KS && (KS <= 8 || ntb <= 2)) return "pw_stream_kernel";
+    return "pw_gemm_kernel";
+}
+
 int launch_pw(bool in_f32, bool out_f32, const PwArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.K <= 0 || a.K % 8 || a.e.cout % 8 || a.KS != cdiv(a.K, 16) || a.NT != cdiv(a.e.cout, 32))
         FR_FAIL(FR_ERR_ARG, "pw: inconsistent shapes (K and Cout must be multiples of 8)");

@@ -15,6 +15,7 @@ struct PwArgs {
     int ntg;              // set by the launcher: n-tiles per column group (large-K kernel)
 };
 int launch_pw(bool in_f32, bool out_f32, const PwArgs& a, hipStream_t st);
+const char* pw_kernel_name(bool in_f32, bool out_f32, int K, int cout, bool se, int HW);
 // Small-M form (M = batch): SE fc layers, Linear(+BN1d).  fp32 output, no SE scale, no residual.
 int launch_fc(bool in_f32, const PwArgs& a, hipStream_t st);
 // LDS bytes per (n-tile, k-step) = 1024 * NS; used by the planner to pick chunk_ks.

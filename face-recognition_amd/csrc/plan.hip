@@ -566,9 +566,18 @@ extern "C" int fr_embed_profile(const fr_plan* plan, const float* x, int batch, 
 
 extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char** name) {
     if (!plan || layer < 0 || layer >= (int)plan->layers.size() || !name) FR_FAIL(FR_ERR_ARG, "fr_plan_layer_kernel: bad layer");
-    static const char* names[] = {"stem_kernel", "pw_gemm_kernel", "dw_kernel", "reduce_kernel", "se(reduce+2xfc)",
-                                  "fc_kernel", "conv3x3_kernel"};
-    *name = names[plan->layers[layer].kind];
+    static const char* names[] = {"stem_kernel", "pw_gemm_kernel", "dw_kernel", "reduce_kernel", "se(reduce_kernel+2xfc_kernel)",
+                                  "fc_kernel", "conv_glds_kernel"};
+    const Layer& L = plan->layers[layer];
+    *name = names[L.kind];
+    if (L.kind == K_PW) {
+        const bool se = L.src >= 0 && plan->layers[L.src].kind == K_SE;
+        *name = pw_kernel_name(L.in_f32, L.out_f32, L.K, L.cout, se, L.H * L.W);
+    } else if (L.kind == K_CONV3 && L.in_f32) {
+        *name = "conv_gemm_kernel";
+    } else if (L.kind == K_LINEAR && L.via_conv) {
+        *name = L.in_f32 ? "conv_gemm_kernel" : "conv_glds_kernel";
+    }
     return FR_OK;
 }
 
