@@ -313,7 +313,10 @@ static int launch_pw_proj(const PwArgs& a, hipStream_t st) {
 // Each wave owns MT consecutive 32-pixel tiles per iteration and issues ALL their activation (and
 // residual) loads before the first MFMA, so that >= 2-4 KB per wave are in flight: the op is pure
 // HBM streaming and bytes in flight per CU, not arithmetic, set its speed.
-template <typename TOut, int NTB, int MT, int KSM = 8 / MT>     // KSM: max k-steps
+// KSM: max k-steps.  SG: n-tiles staged together for the coalesced write-back; SG = NTB when the
+// block covers whole output rows (one column group), so that the 32-pixel tile leaves as ONE linear
+// run (a trailing 8- or 16-channel group of its own would again write 16/32-byte pieces).
+template <typename TOut, int NTB, int MT, int KSM = 8 / MT, int SG = (NTB < 2 ? NTB : 2)>
 __global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -343,7 +346,6 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a) {
     const long n_iter = (a.M + per_iter - 1) / per_iter;
     const int cout = a.e.cout;
     constexpr bool STAGED = std::is_same<TOut, bf16>::value;
-    constexpr int SG = NTB < 2 ? NTB : 2;                         // n-tiles staged together: 128-byte rows
     constexpr int PITCH = stage_pitch(SG * 64);
     unsigned char* stage = smem + (size_t)NTB * KS * 1024 + (size_t)NTB * 256 + (size_t)wave * 32 * PITCH;
 
@@ -510,20 +512,30 @@ void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks) {
     *chunk_ks = ck;
 }
 
-template <typename TOut, int NTB>
-static int launch_pw_stream(const PwArgs& a, hipStream_t st) {
+template <typename TOut, int NTB, int SG>
+static int launch_pw_stream_sg(const PwArgs& a, hipStream_t st) {
     const int mt = a.KS <= 2 ? 4 : (a.KS <= 4 ? 2 : (a.KS <= 8 ? 1 : 0));
     const long per_iter = 128L * (mt ? mt : 1);
     const long n_iter = (a.M + per_iter - 1) / per_iter;
     dim3 grid((unsigned)std::min<long>(n_iter, 2048), (unsigned)cdiv(a.NT, NTB));
     size_t lds = (size_t)NTB * a.KS * 1024 + (size_t)NTB * 256;
-    if (std::is_same<TOut, bf16>::value) lds += 4 * 32 * (size_t)stage_pitch((NTB < 2 ? NTB : 2) * 64);
-    if (mt == 4) { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, 4>), lds); hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 4>), grid, dim3(256), lds, st, a); }
-    else if (mt == 2) { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, 2>), lds); hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 2>), grid, dim3(256), lds, st, a); }
-    else if (mt == 1) { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, 1>), lds); hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 1>), grid, dim3(256), lds, st, a); }
-    else { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, 1, 16>), lds); hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, 1, 16>), grid, dim3(256), lds, st, a); }
+    if (std::is_same<TOut, bf16>::value) lds += 4 * 32 * (size_t)stage_pitch(SG * 64);
+#define FR_PW_GO(MT_, KSM_) do { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, MT_, KSM_, SG>), lds); \
+        hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, MT_, KSM_, SG>), grid, dim3(256), lds, st, a); } while (0)
+    if (mt == 4) FR_PW_GO(4, 2);
+    else if (mt == 2) FR_PW_GO(2, 4);
+    else if (mt == 1) FR_PW_GO(1, 8);
+    else FR_PW_GO(1, 16);
+#undef FR_PW_GO
     FR_LAUNCH_CHECK("pw_stream_kernel");
     return FR_OK;
+}
+
+template <typename TOut, int NTB>
+static int launch_pw_stream(const PwArgs& a, hipStream_t st) {
+    constexpr int SG2 = NTB < 2 ? NTB : 2;
+    if (NTB > 2 && a.NT <= NTB) return launch_pw_stream_sg<TOut, NTB, NTB>(a, st);     // whole rows in one block
+    return launch_pw_stream_sg<TOut, NTB, SG2>(a, st);
 }
 
 template <typename TIn, typename TOut>
