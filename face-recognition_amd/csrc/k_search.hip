@@ -12,7 +12,6 @@
 // index).  Lists of the lanes / waves / gallery splits that share a query are merged by
 // topk_select_kernel.
 #include "kernels.h"
-#include <cstdlib>
 
 #define SEARCH_D 512
 #define SEARCH_KMAX 8
@@ -221,196 +220,6 @@ __global__ __launch_bounds__(256, 2) void search_kernel(SearchArgs a) {
     }
 }
 
-// ---- wide form: 256 queries x 128 gallery rows per block ----------------------------------------
-// Same structure, but each wave owns 128 queries x 64 gallery rows (4 x 2 MFMA tiles), so a k-step
-// needs 6 fragment reads for 8 MFMAs instead of 4 for 4, a K slice moves (256+128) rows into LDS
-// for twice the MACs, and every gallery byte fetched from HBM serves 256 queries: the 128 x 128
-// form keeps the LDS array busy for as long as the MFMA pipe (1 ds_read_b128 per MFMA plus the DMA
-// writes), which is what held it below 40 % of the MFMA peak.  K slices are 32 wide (64-byte LDS
-// rows) so that two 24-KB buffers leave room for two blocks per CU.
-#define W_BK 32
-#define W_ROWB (W_BK * 2)
-#define W_QROWS 256
-#define W_GROWS 128
-#define W_Q_BYTES (W_QROWS * W_ROWB)
-#define W_BUF ((W_QROWS + W_GROWS) * W_ROWB)
-#define W_KSL (SEARCH_D / W_BK)
-#define W_LISTS 4                        // lists per query per split: 2 wave rows (gallery) x 2 lane halves
-
-template <int KK>
-__global__ __launch_bounds__(256, 2) void search_wide_kernel(SearchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int p = lane & 31, h = lane >> 5;
-    const int wg = wave >> 1, wq = wave & 1;                   // wave row (gallery half), wave col (query half)
-    const long q0 = (long)blockIdx.x * W_QROWS;
-    const int split = blockIdx.y;
-    const long tile_begin = (long)split * a.tiles_per_split;
-    const long ntiles_all = (a.G + 127) / 128;
-    const long tile_end = min(tile_begin + a.tiles_per_split, ntiles_all);
-
-    float ts[4][KK]; int ti[4][KK];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < KK; ++e) { ts[j][e] = -INFINITY; ti[j][e] = 0x7FFFFFFF; }
-
-    // staging role: one wave instruction = 16 rows x 64 B; this lane: row sub, physical chunk pc
-    const int sub = lane >> 2, pc = lane & 3;
-    const unsigned char* qsrc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = 16 * (wave + 4 * j) + sub;
-        const int lc = pc ^ ((row >> 2) & 3);
-        const long qr = min(q0 + row, a.Q - 1);
-        qsrc[j] = reinterpret_cast<const unsigned char*>(a.q + qr * SEARCH_D) + lc * 16;
-    }
-    const unsigned char* gbase = reinterpret_cast<const unsigned char*>(a.g);
-    const unsigned char* gsrc[2];
-    auto tile_ptrs = [&](long tile) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = 16 * (wave + 4 * j) + sub;
-            const int lc = pc ^ ((row >> 2) & 3);
-            const long gr = min(tile * 128 + row, a.G - 1);
-            gsrc[j] = gbase + gr * (SEARCH_D * 2) + lc * 16;
-        }
-    };
-    unsigned char* const lbase = smem + S_PAD + wave * 1024;     // see search_kernel: instruction offset moves both addresses
-
-    // per-lane fragment offsets for the 2 k-steps of a slice: logical chunk 2s+h at physical (2s+h) ^ swz(row)
-    int qoff[4][2], goff[2][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wq * 128 + j * 32 + p;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) qoff[j][s] = row * W_ROWB + (((2 * s + h) ^ ((row >> 2) & 3)) << 4);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wg * 64 + i * 32 + p;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) goff[i][s] = W_Q_BYTES + row * W_ROWB + (((2 * s + h) ^ ((row >> 2) & 3)) << 4);
-    }
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-#define W_STAGE(BUFI, KSI)                                                                                         \
-    do {                                                                                                           \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                           \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)qsrc[j_], (lds_ptr_t)(lbase + (BUFI) * W_BUF + j_ * 4096 - (KSI) * W_ROWB), \
-                                             16, (KSI) * W_ROWB, 0);                                               \
-        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                           \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)gsrc[j_],                                                  \
-                                             (lds_ptr_t)(lbase + (BUFI) * W_BUF + W_Q_BYTES + j_ * 4096 - (KSI) * W_ROWB), 16, \
-                                             (KSI) * W_ROWB, 0);                                                   \
-    } while (0)
-
-    if (tile_begin < tile_end) {
-        tile_ptrs(tile_begin);
-        W_STAGE(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-
-#pragma unroll 1
-    for (long tile = tile_begin; tile < tile_end; ++tile) {
-        const bool more = tile + 1 < tile_end;
-        auto slice = [&](auto KSC) {
-            constexpr int ks = decltype(KSC)::value;
-            constexpr int buf = ks & 1;
-            if constexpr (ks + 1 < W_KSL) {
-                W_STAGE(buf ^ 1, ks + 1);
-            } else {
-                if (more) {
-                    tile_ptrs(tile + 1);
-                    W_STAGE(buf ^ 1, 0);
-                }
-            }
-            const unsigned char* bb = smem + S_PAD + buf * W_BUF;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 gf[2], qf[4];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) gf[i] = *reinterpret_cast<const bf16x8*>(bb + goff[i][s]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) qf[j] = *reinterpret_cast<const bf16x8*>(bb + qoff[j][s]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], qf[j], acc[i][j], 0, 0, 0);
-            }
-            if constexpr (ks == W_KSL - 1) {
-                // ---- selection: lane owns query column (wq*128 + j*32 + p); accumulator rows = gallery
-                const long gb = tile * 128 + wg * 64;
-                const bool partial = gb + 64 > a.G;                 // only the last tile can hold rows >= G
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        if (partial) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                if (gb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= a.G) acc[i][j][r] = -INFINITY;
-                        }
-                        float mx = acc[i][j][0];
-#pragma unroll
-                        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][j][r]);
-                        if (__any(mx > ts[j][KK - 1])) {
-                            const int g0 = (int)gb + i * 32 + 4 * h;
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                float sv = acc[i][j][r];
-                                if (sv > ts[j][KK - 1]) {
-                                    int gi = g0 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-                                    for (int e = 0; e < KK; ++e) {
-                                        if (sv > ts[j][e]) {
-                                            const float t = ts[j][e]; ts[j][e] = sv; sv = t;
-                                            const int u = ti[j][e]; ti[j][e] = gi; gi = u;
-                                        }
-                                    }
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-                    }
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        };
-        static_assert(W_KSL == 16, "slice unroll below assumes 16 slices per tile");
-        slice(std::integral_constant<int, 0>{}); slice(std::integral_constant<int, 1>{});
-        slice(std::integral_constant<int, 2>{}); slice(std::integral_constant<int, 3>{});
-        slice(std::integral_constant<int, 4>{}); slice(std::integral_constant<int, 5>{});
-        slice(std::integral_constant<int, 6>{}); slice(std::integral_constant<int, 7>{});
-        slice(std::integral_constant<int, 8>{}); slice(std::integral_constant<int, 9>{});
-        slice(std::integral_constant<int, 10>{}); slice(std::integral_constant<int, 11>{});
-        slice(std::integral_constant<int, 12>{}); slice(std::integral_constant<int, 13>{});
-        slice(std::integral_constant<int, 14>{}); slice(std::integral_constant<int, 15>{});
-    }
-#undef W_STAGE
-
-    // publish this lane's lists
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long qrow = q0 + wq * 128 + j * 32 + p;
-        const int list = wg * 2 + h;
-        const long base = (((long)split * W_LISTS + list) * a.Qpad + qrow) * a.k;
-        for (int e = 0; e < KK; ++e)
-            if (e < a.k) { a.part_s[base + e] = ts[j][e]; a.part_i[base + e] = ti[j][e]; }
-    }
-}
-
 // out[q] = best k of nlists candidate lists (each k long, list stride `lstride` elements),
 // ordered by (score desc, index asc).  One thread per query.
 template <typename TI>
@@ -441,23 +250,20 @@ __global__ void topk_select_kernel(const float* s, const TI* idx, int nlists, lo
     }
 }
 
-static bool search_wide(long Q, int k) { return k <= 5 && Q > 128 && !getenv("FR_SEARCH_NARROW"); }
-
-static void search_geometry(long Q, long G, int k, int* nsplit, long* tiles_per_split, long* Qpad) {
-    const long qt = search_wide(Q, k) ? W_QROWS : 128;
-    const long qtiles = (Q + qt - 1) / qt, gtiles = (G + 127) / 128;
+static void search_geometry(long Q, long G, int* nsplit, long* tiles_per_split, long* Qpad) {
+    const long qtiles = (Q + 127) / 128, gtiles = (G + 127) / 128;
     long ns = (512 + qtiles - 1) / qtiles;         // aim for >= 512 blocks (2 per CU); long splits keep top-k inserts rare
     if (ns > gtiles) ns = gtiles;
     if (ns < 1) ns = 1;
     const long tps = (gtiles + ns - 1) / ns;
     ns = (gtiles + tps - 1) / tps;
-    *nsplit = (int)ns; *tiles_per_split = tps; *Qpad = qtiles * qt;
+    *nsplit = (int)ns; *tiles_per_split = tps; *Qpad = qtiles * 128;
 }
 
 extern "C" int fr_topk_workspace_bytes(int64_t Q, int64_t G, int k, size_t* out_bytes) {
     if (Q <= 0 || G <= 0 || k < 1 || k > SEARCH_KMAX || !out_bytes) FR_FAIL(FR_ERR_ARG, "fr_topk_workspace_bytes: bad arguments");
     int ns; long tps, qpad;
-    search_geometry(Q, G, k, &ns, &tps, &qpad);
+    search_geometry(Q, G, &ns, &tps, &qpad);
     *out_bytes = (size_t)ns * SEARCH_LISTS * qpad * k * 8 + 512;
     return FR_OK;
 }
@@ -476,23 +282,11 @@ extern "C" int fr_topk_search(const uint16_t* q, const uint16_t* g, int64_t Q, i
     SearchArgs a{};
     a.q = reinterpret_cast<const bf16*>(q); a.g = reinterpret_cast<const bf16*>(g);
     a.Q = Q; a.G = G; a.k = k;
-    search_geometry(Q, G, k, &a.nsplit, &a.tiles_per_split, &a.Qpad);
+    search_geometry(Q, G, &a.nsplit, &a.tiles_per_split, &a.Qpad);
     unsigned char* ws = reinterpret_cast<unsigned char*>(align_up((size_t)workspace, 256));
     const size_t nel = (size_t)a.nsplit * SEARCH_LISTS * a.Qpad * k;
     a.part_s = reinterpret_cast<float*>(ws);
     a.part_i = reinterpret_cast<int*>(ws + nel * 4);
-    if (search_wide(Q, k)) {
-        const size_t wlds = 2 * W_BUF + S_PAD;
-        dim3 wgrid((unsigned)(a.Qpad / W_QROWS), (unsigned)a.nsplit);
-        if (k == 1) hipLaunchKernelGGL((search_wide_kernel<1>), wgrid, dim3(256), wlds, st, a);
-        else hipLaunchKernelGGL((search_wide_kernel<5>), wgrid, dim3(256), wlds, st, a);
-        FR_LAUNCH_CHECK("search_wide_kernel");
-        hipLaunchKernelGGL((topk_select_kernel<int>), dim3((unsigned)((Q + 127) / 128)), dim3(128), 0, st,
-                           a.part_s, a.part_i, a.nsplit * W_LISTS, a.Qpad * (long)k, (long)Q, k, (long)idx_offset,
-                           out_scores, out_idx);
-        FR_LAUNCH_CHECK("topk_select_kernel");
-        return FR_OK;
-    }
     const size_t lds = 2 * S_BUF + S_PAD;
     dim3 grid((unsigned)(a.Qpad / 128), (unsigned)a.nsplit);
     static bool attr_set = false;
