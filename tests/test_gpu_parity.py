@@ -141,9 +141,13 @@ def test_batch_sizes_and_determinism(golden_x):
         again = m(x, precision="f32")
         big = m(x.repeat(33, 1, 1, 1), precision="f32")      # 264 images: crosses tile boundaries
         empty = m(x[:0], precision="f32")
+        # 259 images: fr_embed cuts batches >= 128 into two sub-batches (129 + 130) on two streams
+        odd = m(x.repeat(33, 1, 1, 1)[:259], precision="bf16")
+        ref16 = m(x, precision="bf16")
     assert torch.equal(full, again)
     assert torch.equal(full, one)
-    assert torch.equal(big[:8], full) and torch.equal(big[-8:], full)
+    assert torch.equal(big.view(33, 8, -1), full.unsqueeze(0).expand(33, -1, -1))
+    assert torch.equal(odd[:256].view(32, 8, -1), ref16.unsqueeze(0).expand(32, -1, -1)) and torch.equal(odd[256:], ref16[:3])
     assert empty.shape == (0, 512)
 
 
