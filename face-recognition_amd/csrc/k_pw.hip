@@ -22,6 +22,20 @@
 typedef __attribute__((address_space(3))) void* pw_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* pw_glb_ptr_t;
 
+// Pixel-block x / column-group g from a 1-D grid laid out so that the column groups of one pixel
+// block get ids that are equal mod 8 and close together: workgroups are dealt round-robin over the
+// 8 XCDs, so those blocks share an XCD's L2 and read the activations from HBM once, not once per
+// group (measured with FETCH_SIZE: the expansion layers fetched their input up to 15 times).
+struct PwGrid { int gx, ng; };
+FR_DEV bool pw_block(const PwGrid& pg, int& x, int& g) {
+    const int id = blockIdx.x, per = 8 * pg.ng;
+    const int xb = id / per, r = id - xb * per;
+    g = r >> 3;
+    x = xb * 8 + (r & 7);
+    return x < pg.gx;
+}
+static inline unsigned pw_grid_blocks(int gx, int ng) { return (unsigned)(((gx + 7) / 8) * 8 * ng); }
+
 template <typename TIn>
 struct XFrag;
 template <>
@@ -55,7 +69,7 @@ struct XFrag<float> {
 };
 
 template <typename TIn, typename TOut, int NTB>
-__global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
+__global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a, PwGrid pg) {
     constexpr bool SPLIT = std::is_same<TIn, float>::value;
     constexpr int NS = SPLIT ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -63,14 +77,16 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int p = lane & 31, h = lane >> 5;
-    const int t0 = blockIdx.y * NTB;
+    int bx, bg;
+    if (!pw_block(pg, bx, bg)) return;
+    const int t0 = bg * NTB;
     const int nt = min(NTB, a.NT - t0);
     const int nchunks = (a.KS + a.chunk_ks - 1) / a.chunk_ks;
     const long n_super = (a.M + 127) / 128;
     const TIn* X = reinterpret_cast<const TIn*>(a.x);
     bool staged = false;
 
-    for (long st = blockIdx.x; st < n_super; st += gridDim.x) {
+    for (long st = bx; st < n_super; st += pg.gx) {
         const long m = st * 128 + wave * 32 + p;
         const bool m_ok = m < a.M;
         const long mc = m_ok ? m : a.M - 1;
@@ -317,11 +333,13 @@ static int launch_pw_proj(const PwArgs& a, hipStream_t st) {
 // block covers whole output rows (one column group), so that the 32-pixel tile leaves as ONE linear
 // run (a trailing 8- or 16-channel group of its own would again write 16/32-byte pieces).
 template <typename TOut, int NTB, int MT, int KSM = 8 / MT, int SG = (NTB < 2 ? NTB : 2)>
-__global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a) {
+__global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a, PwGrid pg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
-    const int t0 = blockIdx.y * NTB;
+    int bx, bg;
+    if (!pw_block(pg, bx, bg)) return;
+    const int t0 = bg * NTB;
     const int nt = min(NTB, a.NT - t0);
     const int KS = a.KS;
     bf16x8* wl = reinterpret_cast<bf16x8*>(smem);                         // [nt][KS][64]
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a) {
     constexpr int PITCH = stage_pitch(SG * 64);
     unsigned char* stage = smem + (size_t)NTB * KS * 1024 + (size_t)NTB * 256 + (size_t)wave * 32 * PITCH;
 
-    for (long it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    for (long it = bx; it < n_iter; it += pg.gx) {
         const long mbase = it * per_iter + (long)wave * 32 * MT + p;
         bf16x8 xf[MT][KSM];
 #pragma unroll
@@ -517,11 +535,12 @@ static int launch_pw_stream_sg(const PwArgs& a, hipStream_t st) {
     const int mt = a.KS <= 2 ? 4 : (a.KS <= 4 ? 2 : (a.KS <= 8 ? 1 : 0));
     const long per_iter = 128L * (mt ? mt : 1);
     const long n_iter = (a.M + per_iter - 1) / per_iter;
-    dim3 grid((unsigned)std::min<long>(n_iter, 2048), (unsigned)cdiv(a.NT, NTB));
+    const PwGrid pg{(int)std::min<long>(n_iter, 2048), cdiv(a.NT, NTB)};
+    dim3 grid(pw_grid_blocks(pg.gx, pg.ng));
     size_t lds = (size_t)NTB * a.KS * 1024 + (size_t)NTB * 256;
     if (std::is_same<TOut, bf16>::value) lds += 4 * 32 * (size_t)stage_pitch(SG * 64);
 #define FR_PW_GO(MT_, KSM_) do { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, MT_, KSM_, SG>), lds); \
-        hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, MT_, KSM_, SG>), grid, dim3(256), lds, st, a); } while (0)
+        hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, MT_, KSM_, SG>), grid, dim3(256), lds, st, a, pg); } while (0)
     if (mt == 4) FR_PW_GO(4, 2);
     else if (mt == 2) FR_PW_GO(2, 4);
     else if (mt == 1) FR_PW_GO(1, 8);
@@ -552,15 +571,16 @@ static int launch_pw_t(const PwArgs& a, int ntb, hipStream_t st) {
     }
     constexpr int NS = std::is_same<TIn, float>::value ? 2 : 1;
     const long n_super = (a.M + 127) / 128;
-    dim3 grid((unsigned)std::min<long>(n_super, 2048), (unsigned)cdiv(a.NT, ntb));
+    const PwGrid pg{(int)std::min<long>(n_super, 2048), cdiv(a.NT, ntb)};
+    dim3 grid(pw_grid_blocks(pg.gx, pg.ng));
     size_t lds = (size_t)std::min(ntb, a.NT) * a.chunk_ks * NS * 1024;
     PwArgs b = a;
     b.stage_off = (int)lds;
     if (std::is_same<TOut, bf16>::value) lds += 4 * 32 * (size_t)stage_pitch(std::min(ntb, 2) * 64);
     switch (ntb) {
-        case 1: FR_BIG_LDS((pw_gemm_kernel<TIn, TOut, 1>), lds); hipLaunchKernelGGL((pw_gemm_kernel<TIn, TOut, 1>), grid, dim3(256), lds, st, b); break;
-        case 2: FR_BIG_LDS((pw_gemm_kernel<TIn, TOut, 2>), lds); hipLaunchKernelGGL((pw_gemm_kernel<TIn, TOut, 2>), grid, dim3(256), lds, st, b); break;
-        case 4: FR_BIG_LDS((pw_gemm_kernel<TIn, TOut, 4>), lds); hipLaunchKernelGGL((pw_gemm_kernel<TIn, TOut, 4>), grid, dim3(256), lds, st, b); break;
+        case 1: FR_BIG_LDS((pw_gemm_kernel<TIn, TOut, 1>), lds); hipLaunchKernelGGL((pw_gemm_kernel<TIn, TOut, 1>), grid, dim3(256), lds, st, b, pg); break;
+        case 2: FR_BIG_LDS((pw_gemm_kernel<TIn, TOut, 2>), lds); hipLaunchKernelGGL((pw_gemm_kernel<TIn, TOut, 2>), grid, dim3(256), lds, st, b, pg); break;
+        case 4: FR_BIG_LDS((pw_gemm_kernel<TIn, TOut, 4>), lds); hipLaunchKernelGGL((pw_gemm_kernel<TIn, TOut, 4>), grid, dim3(256), lds, st, b, pg); break;
         default: FR_FAIL(FR_ERR_ARG, "pw: bad n-tile blocking");
     }
     FR_LAUNCH_CHECK("pw_gemm_kernel");
