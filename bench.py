@@ -138,8 +138,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true")
-    ap.add_argument("--gallery", type=int, default=0, help="1:N gallery rows (default 10M per GPU, capped at 100M)")
-    ap.add_argument("--queries", type=int, default=4096)
+    ap.add_argument("--gallery", type=int, default=0,
+                    help="1:N gallery rows in total (default: 10M on one GPU = BASELINE.json configs[3]; 100M sharded over the ranks = configs[4])")
+    ap.add_argument("--queries", type=int, default=65536)
     ap.add_argument("--fuse", action="store_true", help="use the fused expand->depthwise kernel (experimental)")
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
     a = ap.parse_args()
@@ -227,8 +228,8 @@ def main():
                 print(f"{name:36s} {kern:22s} {t:8.4f} ms {b / (t * 1e-3) / 1e9 if t > 0 else 0:9.1f} GB/s", file=sys.stderr)
 
     if not a.no_search:
-        ng = a.gallery or min(100_000_000, 10_000_000 * world)
-        res = bench_search(dev, rank, world, max(1, min(a.steps, 3)), 1, ng, a.queries)
+        ng = a.gallery or (10_000_000 if world == 1 else 100_000_000)
+        res = bench_search(dev, rank, world, max(1, min(a.steps, 2)), 1, ng, a.queries)
         if rank == 0:
             line["search"] = res
     if rank == 0 and not a.no_cpu_baseline and world == 1:

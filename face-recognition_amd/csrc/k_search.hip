@@ -260,8 +260,15 @@ static void search_geometry(long Q, long G, int* nsplit, long* tiles_per_split, 
     *nsplit = (int)ns; *tiles_per_split = tps; *Qpad = qtiles * 128;
 }
 
+// Queries are processed in chunks of at most SEARCH_QCHUNK per launch: with more query tiles than
+// resident blocks every block walks the whole gallery on its own schedule and the gallery is
+// streamed from HBM once per block instead of once per XCD (65536 queries in one launch: 632
+// TFLOP/s; in chunks of 16384: 997).
+#define SEARCH_QCHUNK 16384
+
 extern "C" int fr_topk_workspace_bytes(int64_t Q, int64_t G, int k, size_t* out_bytes) {
     if (Q <= 0 || G <= 0 || k < 1 || k > SEARCH_KMAX || !out_bytes) FR_FAIL(FR_ERR_ARG, "fr_topk_workspace_bytes: bad arguments");
+    if (Q > SEARCH_QCHUNK) Q = SEARCH_QCHUNK;
     int ns; long tps, qpad;
     search_geometry(Q, G, &ns, &tps, &qpad);
     *out_bytes = (size_t)ns * SEARCH_LISTS * qpad * k * 8 + 512;
@@ -278,6 +285,15 @@ extern "C" int fr_topk_search(const uint16_t* q, const uint16_t* g, int64_t Q, i
     size_t need = 0;
     fr_topk_workspace_bytes(Q, G, k, &need);
     if (!workspace || workspace_bytes < need) FR_FAIL(FR_ERR_WORKSPACE, "fr_topk_search: workspace too small");
+    if (Q > SEARCH_QCHUNK) {                  // chunks run back to back on the stream and share the workspace
+        for (int64_t c0 = 0; c0 < Q; c0 += SEARCH_QCHUNK) {
+            const int64_t qc = std::min<int64_t>(SEARCH_QCHUNK, Q - c0);
+            const int rc = fr_topk_search(q + c0 * SEARCH_D, g, qc, G, d, k, idx_offset, out_scores + c0 * k, out_idx + c0 * k,
+                                          workspace, workspace_bytes, stream);
+            if (rc) return rc;
+        }
+        return FR_OK;
+    }
     hipStream_t st = (hipStream_t)stream;
     SearchArgs a{};
     a.q = reinterpret_cast<const bf16*>(q); a.g = reinterpret_cast<const bf16*>(g);

@@ -235,7 +235,7 @@ def test_synthetic_rows_bit_exact():
     assert np.array_equal(q.view(torch.int16).cpu().numpy().view(np.uint16), osr.query_rows(11, 0, 33))
 
 
-@pytest.mark.parametrize("Q,G", [(64, 4096), (130, 1000), (1, 129), (257, 20011)])
+@pytest.mark.parametrize("Q,G", [(64, 4096), (130, 1000), (1, 129), (257, 20011), (16384 + 130, 700)])   # last: two query chunks
 def test_topk_search_parity(Q, G):
     npl = min(8, Q)
     g = fr.search.synth_rows(7, 0, G, DEV, plant_seed=11, n_plant=npl, n_gallery_total=G)
@@ -246,12 +246,14 @@ def test_topk_search_parity(Q, G):
     os_, oi, gap = osr.topk_cosine(qf, gf, 5)
     s, i = s.cpu().numpy(), i.cpu().numpy()
     assert np.abs(s - os_).max() <= 1e-3
-    # exact index equality rank by rank wherever neighbouring scores are separated by > 5e-5
-    # (20x tighter than the 1e-3 bar; fp32 accumulation of 512 products is good to ~1e-5)
+    # exact index equality rank by rank wherever neighbouring scores are separated by > 2e-4
+    # (5x tighter than the 1e-3 similarity bar).  The oracle re-normalises the bf16-rounded rows in
+    # float64 while the kernel takes them as unit vectors (their norms are off by ~1e-4 relative), so
+    # scores closer than that can legitimately swap; fp32 accumulation adds ~1e-5.
     full = osr.topk_cosine(qf, gf, 6)[0] if G > 5 else None
     for r in range(Q):
         seps = np.abs(np.diff(np.concatenate([os_[r], [os_[r, -1] - gap[r]]])))
-        ok = seps > 5e-5
+        ok = seps > 2e-4
         clear = np.concatenate([[True], ok[:-1]]) & ok
         assert np.array_equal(i[r][clear], oi[r][clear]), (r, i[r], oi[r])
     for t in range(npl):
