@@ -4,6 +4,7 @@ Host-side mirror of the reference's Python entry points (inference.py, evaluate.
 of libfr_hip.so (include/fr_hip.h).  Import as ``import face_recognition_amd`` (shim at repo root).
 """
 from . import _lib
+from . import ops
 from .models import (HipBackbone, MobileNetV1, MobileNetV2, mobilenet_v3_large, mobilenet_v3_small,
                      sphere20, sphere36, sphere64, default_precision)
 from .inference import (get_network, load_model, get_transform, extract_features, extract_batch_embeddings,

@@ -130,15 +130,7 @@ def cosine_pairs(a: torch.Tensor, b: torch.Tensor, eps: float = 0.0, threshold: 
     b = b.to(torch.float32).contiguous()
     if a.shape != b.shape or a.dim() != 2:
         raise ValueError("cosine_pairs: expected two [P,d] tensors of equal shape")
-    P, d = a.shape
-    sim = torch.empty(P, dtype=torch.float32, device=a.device)
-    dec = torch.empty(P, dtype=torch.uint8, device=a.device)
-    if P:
-        with torch.cuda.device(a.device):
-            _lib.check(_lib.lib().fr_cosine_pairs(a.data_ptr(), b.data_ptr(), P, d, C.c_float(eps), C.c_double(threshold),
-                                                  sim.data_ptr(), dec.data_ptr(),
-                                                  torch.cuda.current_stream(a.device).cuda_stream), "fr_cosine_pairs")
-    return sim, dec.bool()
+    return torch.ops.fr_hip.cosine_pairs(a, b, float(eps), float(threshold))       # ops.py -> fr_cosine_pairs
 
 
 def compute_similarity(feat1: np.ndarray, feat2: np.ndarray) -> np.float32:

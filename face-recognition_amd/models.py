@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from . import ops
 
 __all__ = ["MobileNetV1", "MobileNetV2", "mobilenet_v3_small", "mobilenet_v3_large",
            "sphere20", "sphere36", "sphere64", "HipBackbone", "default_precision"]
@@ -225,6 +226,7 @@ class _Plan:
 
     def close(self) -> None:
         if self.handle:
+            ops.drop_workspace(int(self.handle.value))
             self.lib.fr_plan_destroy(self.handle)
             self.handle = None
 
@@ -266,13 +268,12 @@ class _Plan:
                           dtype=torch.float32, device=x.device)
         if n == 0:
             return out if tap < 0 else (out, None)
+        if tap < 0:
+            c, h, w = self.dims[-1]
+            return torch.ops.fr_hip.embed(x, int(self.handle.value), c, h, w)      # ops.py -> fr_embed
         ws = self.workspace(n)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         with torch.cuda.device(x.device):
-            if tap < 0:
-                _lib.check(self.lib.fr_embed(self.handle, x.data_ptr(), n, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                             stream), "fr_embed")
-                return out
             tap_out = torch.empty((n,) + self.dims[tap], dtype=torch.float32, device=x.device)
             _lib.check(self.lib.fr_embed_tap(self.handle, x.data_ptr(), n, out.data_ptr(), ws.data_ptr(), ws.numel(),
                                              stream, tap, tap_out.data_ptr()), "fr_embed_tap")

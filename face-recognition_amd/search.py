@@ -47,13 +47,7 @@ def normalize_rows_bf16(x: torch.Tensor) -> torch.Tensor:
     """fp32 [n,512] embeddings -> L2-normalised bf16 rows (gallery/query format)."""
     if not x.is_cuda:
         raise RuntimeError("normalize_rows_bf16 needs a GPU tensor: the hot path has no CPU fallback")
-    x = x.to(torch.float32).contiguous()
-    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    if x.shape[0]:
-        with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().fr_l2norm_bf16(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
-                                                 _stream(x.device)), "fr_l2norm_bf16")
-    return out
+    return torch.ops.fr_hip.l2norm_bf16(x.to(torch.float32).contiguous())          # ops.py -> fr_l2norm_bf16
 
 
 def l2norm(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -87,25 +81,7 @@ class Matcher:
         """q bf16 [Q,512] -> (scores fp32 [Q,k] descending, indices int64 [Q,k] global)."""
         if q.dtype != torch.bfloat16 or q.dim() != 2 or q.shape[1] != DIM or q.device != self.g.device:
             raise ValueError("queries must be bf16 [Q,512] on the gallery's device")
-        q = q.contiguous()
-        Q, G = q.shape[0], self.g.shape[0]
-        scores = torch.empty((Q, self.k), dtype=torch.float32, device=q.device)
-        idx = torch.empty((Q, self.k), dtype=torch.int64, device=q.device)
-        if Q == 0:
-            return scores, idx
-        if G == 0:
-            return scores.fill_(float("-inf")), idx.fill_(-1)
-        lib = _lib.lib()
-        need = C.c_size_t()
-        _lib.check(lib.fr_topk_workspace_bytes(Q, G, self.k, C.byref(need)), "fr_topk_workspace_bytes")
-        if self._ws is None or self._ws.numel() < need.value:
-            self._ws = None
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=q.device)
-        with torch.cuda.device(q.device):
-            _lib.check(lib.fr_topk_search(q.data_ptr(), self.g.data_ptr(), Q, G, DIM, self.k, self.idx_offset,
-                                          scores.data_ptr(), idx.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
-                                          _stream(q.device)), "fr_topk_search")
-        return scores, idx
+        return torch.ops.fr_hip.topk_search(q.contiguous(), self.g, self.k, self.idx_offset)   # ops.py -> fr_topk_search
 
 
 def merge_topk(scores: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -117,13 +93,7 @@ def merge_topk(scores: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.T
     P, Q, kk = scores.shape
     if kk != k:
         raise ValueError("merge_topk: list length must equal k")
-    out_s = torch.empty((Q, k), dtype=torch.float32, device=scores.device)
-    out_i = torch.empty((Q, k), dtype=torch.int64, device=scores.device)
-    if Q:
-        with torch.cuda.device(scores.device):
-            _lib.check(_lib.lib().fr_topk_merge(scores.data_ptr(), idx.data_ptr(), P, Q, k, out_s.data_ptr(),
-                                                out_i.data_ptr(), _stream(scores.device)), "fr_topk_merge")
-    return out_s, out_i
+    return torch.ops.fr_hip.topk_merge(scores, idx, k)                             # ops.py -> fr_topk_merge
 
 
 def all_gather_topk(scores: torch.Tensor, idx: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -134,3 +134,17 @@ def test_sharded_exchange_world_size_2_gloo():
     res = [q.get(timeout=120) for _ in procs]
     [p.join(60) for p in procs]
     assert all(ok for _, ok, _ in res) and all(shape == (2, 16, 5) for _, _, shape in res)
+
+
+def test_custom_ops_registered_and_refuse_cpu():
+    """The hot path is reached through torch.library ops (namespace fr_hip) that exist for the
+    CUDA/ROCm dispatch key only: a CPU tensor must be refused, never silently computed."""
+    import torch
+    for name in ("embed", "cosine_pairs", "l2norm_bf16", "topk_search", "topk_merge"):
+        assert hasattr(torch.ops.fr_hip, name)
+    with pytest.raises(NotImplementedError):
+        torch.ops.fr_hip.cosine_pairs(torch.zeros(2, 8), torch.zeros(2, 8), 0.0, 0.35)
+    with pytest.raises(NotImplementedError):
+        torch.ops.fr_hip.topk_search(torch.zeros(2, 512, dtype=torch.bfloat16), torch.zeros(4, 512, dtype=torch.bfloat16), 5, 0)
+    y = torch.ops.fr_hip.embed(torch.zeros(3, 3, 112, 112, device="meta"), 0, 512, 1, 1)
+    assert tuple(y.shape) == (3, 512) and y.dtype == torch.float32
