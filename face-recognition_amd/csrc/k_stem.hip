@@ -13,10 +13,10 @@
 template <typename TOut, bool SPLIT>
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
     constexpr int NS = SPLIT ? 2 : 1;
-    constexpr int TH = 8, TW = 16;
+    constexpr int TH = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* patch = reinterpret_cast<float*>(smem);
-    const int S = a.stride;
+    const int S = a.stride, TW = a.TW;              // TW: multiple of 8, up to the whole output row
     const int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
     const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
     int b = blockIdx.x;
@@ -25,69 +25,114 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
     const int n = b;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int gy0 = oy0 * S - 1, gx0 = ox0 * S - 1;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
-    for (int i = threadIdx.x; i < 3 * IH * IW; i += 256) {
-        const int c = i / (IH * IW); const int rem = i - c * IH * IW;
-        const int iy = rem / IW, ix = rem - iy * IW;
-        const int gy = gy0 + iy, gx = gx0 + ix;
-        float v = 0.f;
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = a.x[(((long)n * 3 + c) * a.H + gy) * a.W + gx];
-        patch[i] = v;
+    // fp32 patch by LDS-DMA, 4 bytes per lane (lane after lane = the row-major patch); every copy is
+    // issued before the single wait; pixels outside the image read the zero page.  A block owns an
+    // 8-row strip of (up to) the whole image width: 100 k tiny blocks of 8x16 pixels were bound by
+    // workgroup turnover, not by memory.
+    {
+        const int total = 3 * IH * IW;
+        const FastDiv d_hw(IH * IW), d_w(IW);
+        for (int i0 = wave * 64; i0 < total; i0 += 256) {
+            const int i = i0 + lane;
+            if (i < total) {
+                unsigned c, rem, iy, ix;
+                d_hw.divmod(i, c, rem);
+                d_w.divmod(rem, iy, ix);
+                const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
+                const float* src = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                                       ? a.x + (((long)n * 3 + c) * a.H + gy) * a.W + gx : reinterpret_cast<const float*>(a.zeros);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(patch + i0), 4, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
-    const int py = 4 * (wave >> 1) + (p >> 3), px = 8 * (wave & 1) + (p & 7);
-    const int base = py * S * IW + px * S;
-
-    bf16x8 xh[2], xl[2];
+    // per-lane LDS offsets of the 16 im2col taps this lane feeds (k = 16 s + 8 h + j = c*9 + ky*3 + kx)
+    int koff[2][8];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        Vec8f v;
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 16 * s + 8 * h + j;
             const int c = k / 9, r9 = k - 9 * c;
             const int ky = r9 / 3, kx = r9 - 3 * ky;
-            v.v[j] = k < 27 ? patch[c * IH * IW + ky * IW + kx + base] : 0.f;
+            koff[s][j] = k < 27 ? c * IH * IW + ky * IW + kx : -1;
         }
-        if constexpr (SPLIT) split8(v, xh[s], xl[s]);
-        else xh[s] = to_frag(v);
-    }
-
-    const int gy = oy0 + py, gx = ox0 + px;
-    const bool ok = gy < a.Ho && gx < a.Wo;
-    const long m = ((long)n * a.Ho + gy) * a.Wo + gx;
     const bf16x8* W = reinterpret_cast<const bf16x8*>(a.w);
-    for (int t = 0; t < a.NT; ++t) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nsub_x = TW >> 3, nsub = 2 * nsub_x;              // 4x8-pixel sub-tiles of the strip
+    for (int st = wave; st < nsub; st += 4) {
+        const int sy = st / nsub_x, sx = st - sy * nsub_x;
+        const int py = 4 * sy + (p >> 3), px = 8 * sx + (p & 7);
+        const int base = py * S * IW + px * S;
+        bf16x8 xh[2], xl[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const bf16x8* wf = W + ((t * 2 + s) * NS) * 64 + lane;
-            bf16x8 wh = wf[0];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], acc, 0, 0, 0);
-            if constexpr (SPLIT) {
-                bf16x8 wl = wf[64];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[s], acc, 0, 0, 0);
+            Vec8f v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v.v[j] = koff[s][j] >= 0 ? patch[koff[s][j] + base] : 0.f;
+            if constexpr (SPLIT) split8(v, xh[s], xl[s]);
+            else xh[s] = to_frag(v);
+        }
+        const int gy = oy0 + py, gx = ox0 + px;
+        const bool ok = gy < a.Ho && gx < a.Wo;
+        const long m = ((long)n * a.Ho + gy) * a.Wo + gx;
+        for (int t = 0; t < a.NT; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8* wf = W + ((t * 2 + s) * NS) * 64 + lane;
+                bf16x8 wh = wf[0];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], acc, 0, 0, 0);
+                if constexpr (SPLIT) {
+                    bf16x8 wl = wf[64];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[s], acc, 0, 0, 0);
+                }
+            }
+            if constexpr (std::is_same<TOut, bf16>::value) {
+                // wave-private [32 pixels][32 channels] tile in LDS, written back as contiguous runs of 8 pixels
+                constexpr int PITCH = 64 + 16;
+                unsigned char* stage = smem + a.stage_off + wave * 32 * PITCH;
+                epilogue_stage(acc, a.e, m, 32 * t + 16 * h, true, stage, PITCH, p, 16 * h);
+                const int ncol = min(32, a.e.cout - 32 * t), cr = ncol >> 3;       // 16-byte chunks per pixel: 1..4
+                __builtin_amdgcn_wave_barrier();
+                for (int c = lane; c < 32 * cr; c += 64) {
+                    const int q = c / cr, ch = c - q * cr;
+                    const int y = oy0 + 4 * sy + (q >> 3), xx = ox0 + 8 * sx + (q & 7);
+                    if (y < a.Ho && xx < a.Wo) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + q * PITCH + ch * 16);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(a.e.y) + (((long)n * a.Ho + y) * a.Wo + xx) * a.e.cout + 32 * t + ch * 8) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                epilogue_store<TOut>(acc, a.e, m, 32 * t + 16 * h, ok);
             }
         }
-        epilogue_store<TOut>(acc, a.e, m, 32 * t + 16 * h, ok);
     }
 }
 
 int launch_stem(bool out_f32, const StemArgs& a, hipStream_t st) {
     if (a.e.cout % 8 || a.NT != cdiv(a.e.cout, 32) || (a.stride != 1 && a.stride != 2))
         FR_FAIL(FR_ERR_ARG, "stem: inconsistent shapes");
-    const int IH = 7 * a.stride + 3, IW = 15 * a.stride + 3;
-    const size_t lds = (size_t)3 * IH * IW * sizeof(float);
-    const long blocks = (long)a.N * cdiv(a.Ho, 8) * cdiv(a.Wo, 16);
+    if (!a.zeros) FR_FAIL(FR_ERR_ARG, "stem: no zero page");
+    StemArgs b = a;
+    b.TW = std::min(112, cdiv(a.Wo, 8) * 8);
+    const int IH = 7 * a.stride + 3, IW = (b.TW - 1) * a.stride + 3;
+    size_t lds = align_up((size_t)3 * IH * IW * sizeof(float), 16);
+    b.stage_off = (int)lds;
+    if (!out_f32) lds += 4 * 32 * (64 + 16);
+    const long blocks = (long)a.N * cdiv(a.Ho, 8) * cdiv(a.Wo, b.TW);
     if (blocks > 0x7FFFFFFFL) FR_FAIL(FR_ERR_ARG, "stem: grid too large");
-    if (out_f32) hipLaunchKernelGGL((stem_kernel<float, true>), dim3((unsigned)blocks), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((stem_kernel<bf16, false>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    if (out_f32) hipLaunchKernelGGL((stem_kernel<float, true>), dim3((unsigned)blocks), dim3(256), lds, st, b);
+    else hipLaunchKernelGGL((stem_kernel<bf16, false>), dim3((unsigned)blocks), dim3(256), lds, st, b);
     FR_LAUNCH_CHECK("stem_kernel");
     return FR_OK;
 }

@@ -52,6 +52,9 @@ struct StemArgs {
     const bf16* w;        // packed [NT][2][NS][64][8]
     EpiArgs e;
     int N, H, W, Ho, Wo, stride, NT;
+    const void* zeros;    // >= 16 B of device zeros (LDS-DMA source outside the image)
+    int stage_off;        // set by the launcher: LDS offset of the output staging tiles
+    int TW;               // set by the launcher: output columns per block (8-row strips)
 };
 int launch_stem(bool out_f32, const StemArgs& a, hipStream_t st);
 

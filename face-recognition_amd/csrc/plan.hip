@@ -481,6 +481,7 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
                 a.x = x; a.w = L.w_packed;
                 a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act};
                 a.N = N; a.H = L.inH; a.W = L.inW; a.Ho = L.H; a.Wo = L.W; a.stride = L.stride; a.NT = L.NT;
+                a.zeros = plan->zeros;
                 rc = launch_stem(L.out_f32, a, st);
                 break;
             }
