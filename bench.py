@@ -141,7 +141,6 @@ def main():
     ap.add_argument("--gallery", type=int, default=0,
                     help="1:N gallery rows in total (default: 10M on one GPU = BASELINE.json configs[3]; 100M sharded over the ranks = configs[4])")
     ap.add_argument("--queries", type=int, default=65536)
-    ap.add_argument("--fuse", action="store_true", help="use the fused expand->depthwise kernel (experimental)")
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
     a = ap.parse_args()
 
@@ -156,9 +155,6 @@ def main():
     torch.manual_seed(0)
     model = fr.get_network(a.model).to(dev).eval()
     model.precision = a.precision
-    if a.fuse:
-        _plan = model.plan
-        model.plan = lambda device, precision=None, fuse=None: _plan(device, precision, True)
     x = synthetic_batch(a.batch, dev)
     with torch.no_grad():
         for _ in range(a.warmup):

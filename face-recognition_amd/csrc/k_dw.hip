@@ -92,11 +92,12 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- compute
-    for (int it = threadIdx.x; it < g.nitems; it += 256) {
+    // ---- compute.  item(): one strip of SW outputs x 8 channels; psum receives the sum of the valid,
+    // activated outputs (squeeze-excite pooling) when a.pool is set.
+    auto item = [&](int it, float* psum) {
         const unsigned r = div32(it, g.d_cbv), cv = it - r * CBV;
         const unsigned oy = div32(r, g.d_ns), sx = r - oy * g.nstrips;
-        if ((int)cv >= ncv) continue;
+        if ((int)cv >= ncv) return;
         float acc[SW][8];
         {
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl + (0 * CBV + cv) * 4);
@@ -151,10 +152,42 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v.v[j] = acc[o][j];
                     act8(v, a.act, sl);
+                    if (psum) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) psum[j] += v.v[j];
+                    }
                     store8(reinterpret_cast<T*>(Yn + yoff + o * a.C * (int)sizeof(T)), v);
                 }
             }
         }
+    };
+
+    if (!a.pool) {
+        for (int it = threadIdx.x; it < g.nitems; it += 256) item(it, nullptr);
+        return;
+    }
+    // pooled form (nitems <= 512, checked by the launcher): per-item sums -> LDS -> fixed-order
+    // reduction per channel -> pool[n][tile][c].  Deterministic: no atomics.
+    float ps0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ps1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((int)threadIdx.x < g.nitems) item(threadIdx.x, ps0);
+    if ((int)threadIdx.x + 256 < g.nitems) item(threadIdx.x + 256, ps1);
+    __syncthreads();                                   // every wave is done reading the input tile
+    float* sums = reinterpret_cast<float*>(smem);      // [nitems][8], aliases the tile
+    if ((int)threadIdx.x < g.nitems) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sums[threadIdx.x * 8 + j] = ps0[j];
+    }
+    if ((int)threadIdx.x + 256 < g.nitems) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sums[(threadIdx.x + 256) * 8 + j] = ps1[j];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ncv * 8) {
+        const int cv = threadIdx.x >> 3, j = threadIdx.x & 7;
+        const int per = g.nitems / CBV;                // items per channel vector: it = r * CBV + cv
+        float t = 0.f;
+        for (int r = 0; r < per; ++r) t += sums[(r * CBV + cv) * 8 + j];
+        a.pool[((size_t)n * a.pool_tiles + (size_t)ty * a.tiles_x + tx) * a.C + (cv0 + cv) * 8 + j] = t;
     }
 }
 
@@ -181,6 +214,7 @@ static void dw_pick_tile(bool f32, int k, int s, DwArgs& a) {
             if (dw_lds_bytes(f32, k, s, th, tw, cbv) > 40 * 1024) continue;
             const int tyc = cdiv(a.Ho, th), txc = cdiv(a.Wo, tw), ccs = cdiv(CV, cbv);
             const int items = th * (tw / sw) * cbv;
+            if (items > 512) continue;                      // two passes at most (the pooled form keeps per-pass sums in registers)
             const double passes = cdiv(items, 256);
             const double IH = (th - 1) * s + k, IW = (tw - 1) * s + k;
             // cost ~ compute passes + staged input vectors / 256 (load loop), per useful output
@@ -206,6 +240,13 @@ static int launch_dw_t(int k, int s, const DwArgs& a, DwGeom g, size_t lds, hipS
     return FR_OK;
 }
 
+int dw_tiles_per_image(bool f32, int k, int stride, int C, int Ho, int Wo) {
+    DwArgs a{};
+    a.C = C; a.Ho = Ho; a.Wo = Wo; a.TH = 0;
+    dw_pick_tile(f32, k, stride, a);
+    return a.TH ? a.tiles_y * a.tiles_x : 0;
+}
+
 int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st) {
     if (a.C % 8 || a.N <= 0) FR_FAIL(FR_ERR_ARG, "depthwise: C must be a multiple of 8");
     if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: only k in {3,5}, stride in {1,2}");
@@ -226,6 +267,7 @@ int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st) {
     if (a.tiles_y > 65535 || (long)a.tiles_x * a.cchunks > 0x7FFFFFFFL) FR_FAIL(FR_ERR_ARG, "depthwise: grid too large");
     const size_t lds = dw_lds_bytes(f32, k, stride, a.TH, a.TW, a.CBV);
     if (lds > 64 * 1024) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: tile above 64 KB of LDS");
+    if (a.pool && a.pool_tiles != a.tiles_y * a.tiles_x) FR_FAIL(FR_ERR_ARG, "depthwise: pool buffer sized for another tiling");
     DwGeom g{};
     const int sw = stride == 2 ? 2 : 4;
     g.IH = (a.TH - 1) * stride + k; g.IW = (a.TW - 1) * stride + k;
@@ -233,5 +275,6 @@ int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st) {
     g.nitems = a.TH * g.nstrips * a.CBV;
     g.nunits = g.IH * g.IW * a.CBV * (f32 ? 2 : 1);
     g.d_cbv = make_div32(a.CBV); g.d_iw = make_div32(g.IW); g.d_ns = make_div32(g.nstrips);
+    if (a.pool && g.nitems > 512) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: pooled form needs <= 512 work items per tile");
     return f32 ? launch_dw_t<float>(k, stride, a, g, lds, st) : launch_dw_t<bf16>(k, stride, a, g, lds, st);
 }

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
         float t = 0.f;
         for (int q = 0; q < PS; ++q) t += part[(q * ncv + c) * 8 + j];   // fixed order: deterministic
         const int cg = (cv0 + c) * 8 + j;
-        if (!a.w) t *= 1.f / (float)a.P;
+        if (!a.w) t *= a.scale != 0.f ? a.scale : 1.f / (float)a.P;
         if (a.bias) t += a.bias[cg];
         a.out[(long)n * a.C + cg] = t;
     }

@@ -32,19 +32,12 @@ struct DwArgs {
     int TH, TW, CBV;      // output tile (TW multiple of 4) and channel-vectors (8 ch) per block
     int tiles_x, tiles_y, cchunks;
     const void* zeros;    // >= 16 B of device zeros: LDS-DMA source for out-of-image taps and absent slopes
+    float* pool;          // optional [N][pool_tiles][C] per-tile channel sums of the OUTPUT (squeeze-excite pooling), or NULL
+    int pool_tiles;       // tiles per image the caller sized `pool` for (must equal dw_tiles_per_image)
 };
+// Spatial tiles per image launch_dw will use for this layer shape (sizes DwArgs::pool).
+int dw_tiles_per_image(bool f32, int k, int stride, int C, int Ho, int Wo);
 int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st);
-
-// ---- fused expand 1x1 (+BN+act) -> depthwise KxK (+BN+act); dw.x is the block input [N,H,W,Cin]
-struct XdwArgs {
-    DwArgs dw;
-    const bf16* we;       // expand weights, packed as for the pointwise kernel [NT][KS][NS][64][8]
-    const float* bias_e;  // [cexp_pad32]
-    const float* slope_e; // [cexp_pad32] or NULL
-    int act_e, Cin, KS;
-};
-int launch_xdw(bool f32, int k, int stride, XdwArgs a, hipStream_t st);
-bool xdw_supported(int Cin, int k, int stride);
 
 // ---- 3x3 stem conv, Cin = 3, fp32 NCHW in -> NHWC out, MFMA with K = 27 (padded to 32)
 struct StemArgs {
@@ -78,6 +71,7 @@ struct ReduceArgs {
     const float* bias;    // [C] or NULL
     float* out;           // [N,C] fp32
     int N, P, C;
+    float scale;          // w == NULL: multiply the sum by this instead of 1/P when non-zero
 };
 int launch_reduce(bool f32, const ReduceArgs& a, hipStream_t st);
 

@@ -27,6 +27,7 @@ struct Layer {
     bool in_f32 = false;
     int slot = -1;                        // output slot
     int slot_pool = -1, slot_hidden = -1; // SE extras (fp32 [N,C], [N,S]); slot = scale [N,C]
+    int slot_partial = -1, pool_tiles = 0; // depthwise feeding an SE block: per-tile channel sums [N,pool_tiles,C] fp32
     // device parameters
     bf16* w_packed = nullptr;             // GEMM-shaped kernels
     bf16* w_packed2 = nullptr;            // SE fc2
@@ -38,8 +39,8 @@ struct Layer {
     int K2 = 0, KS2 = 0, NT2 = 0, chunk_ks2 = 0;   // SE fc2 geometry
     int conv_bk = 32;                     // K-slice width the conv weights were packed with
     bool via_conv = false;                // Linear routed through the conv implicit-GEMM kernel
-    bool fused_next = false;              // expand 1x1 conv computed inside the next (depthwise) layer's kernel
-    int fuse_src = -1;                    // depthwise layer: index of the expand conv fused into it
+    bool fused_next = false;              // (reserved: a layer computed inside the next layer's kernel; none today)
+    int fuse_src = -1;
 };
 
 }  // namespace
@@ -354,18 +355,9 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         if (L.residual == -1 && false) {}
     }
     last_use[n - 1] = n;   // final output stays live
-    // expand(1x1) -> depthwise fusion: the expanded tensor never leaves LDS (k_xdw.hip)
-    for (int i = 0; !no_fuse && i + 1 < n; ++i) {
-        Layer& E = pl->layers[i];
-        Layer& D = pl->layers[i + 1];
-        if (E.kind == K_PW && E.residual < 0 && D.kind == K_DW && D.src == i && last_use[i] == i + 1 &&
-            !(E.src >= 0 && pl->layers[E.src].kind == K_SE) && xdw_supported(E.K, D.k, D.stride)) {
-            E.fused_next = true;
-            D.fuse_src = i;
-            if (E.src >= 0) last_use[E.src] = std::max(last_use[E.src], i + 1);
-            else if (need_input_copy) input_last_use = std::max(input_last_use, i + 1);
-        }
-    }
+    // (An expand(1x1)->depthwise fused kernel existed in round 1: bit-identical but slower than the two
+    // launches, so it was removed; FR_PLAN_NO_FUSE is still accepted and has no effect.)
+    (void)no_fuse;
     std::vector<size_t>& sizes = pl->slot_bytes;
     std::vector<char> busy;
     if (need_input_copy) pl->input_slot = alloc_slot(sizes, busy, (size_t)in_c * in_h * in_w * pl->act_bytes());
@@ -382,8 +374,18 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         } else {
             L.slot = alloc_slot(sizes, busy, layer_out_bytes(L));
             launches += 1;
+            // depthwise -> squeeze-excite: the depthwise kernel also emits per-tile channel sums, so the
+            // SE block never re-reads the activation (freed again once the SE layer has run)
+            static const bool se_fuse = !(getenv("FR_SE_FUSE") && atoi(getenv("FR_SE_FUSE")) == 0);
+            if (se_fuse && L.kind == K_DW && L.fuse_src < 0 && i + 1 < n && pl->layers[i + 1].kind == K_SE && pl->layers[i + 1].src == i) {
+                const int T = dw_tiles_per_image(L.in_f32, L.k, L.stride, L.C, L.H, L.W);
+                if (T > 0) { L.pool_tiles = T; L.slot_partial = alloc_slot(sizes, busy, (size_t)T * L.C * 4); }
+            }
         }
-        if (L.kind == K_SE) { busy[L.slot_pool] = 0; busy[L.slot_hidden] = 0; }
+        if (L.kind == K_SE) {
+            busy[L.slot_pool] = 0; busy[L.slot_hidden] = 0;
+            if (pl->layers[L.src].slot_partial >= 0) busy[pl->layers[L.src].slot_partial] = 0;
+        }
         for (int j = 0; j < i; ++j)
             if (last_use[j] == i && pl->layers[j].slot >= 0) busy[pl->layers[j].slot] = 0;
         if (last_use[i] < 0 && L.slot >= 0) busy[L.slot] = 0;   // dead output (only reachable through taps)
@@ -516,16 +518,8 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
                 a.x = xin; a.w = L.w_f32; a.bias = L.bias; a.slope = L.slope; a.y = y;
                 a.N = N; a.H = L.inH; a.W = L.inW; a.C = L.C; a.Ho = L.H; a.Wo = L.W; a.pad = L.pad; a.act = L.act;
                 a.zeros = plan->zeros;
-                if (L.fuse_src >= 0) {
-                    const Layer& E = plan->layers[L.fuse_src];
-                    XdwArgs xa{};
-                    xa.dw = a;
-                    xa.dw.x = E.src < 0 ? in_nhwc : (const void*)base[plan->layers[E.src].slot];
-                    xa.we = E.w_packed; xa.bias_e = E.bias; xa.slope_e = E.slope; xa.act_e = E.act; xa.Cin = E.K; xa.KS = E.KS;
-                    rc = launch_xdw(L.in_f32, L.k, L.stride, xa, st);
-                } else {
-                    rc = launch_dw(L.in_f32, L.k, L.stride, a, st);
-                }
+                if (L.slot_partial >= 0) { a.pool = reinterpret_cast<float*>(base[L.slot_partial]); a.pool_tiles = L.pool_tiles; }
+                rc = launch_dw(L.in_f32, L.k, L.stride, a, st);
                 break;
             }
             case K_GDW: {
@@ -536,8 +530,14 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
             case K_SE: {
                 float* pool = reinterpret_cast<float*>(base[L.slot_pool]);
                 float* hid = reinterpret_cast<float*>(base[L.slot_hidden]);
-                ReduceArgs r{xin, nullptr, nullptr, pool, N, L.H * L.W, L.C};
-                rc = launch_reduce(L.in_f32, r, st);
+                const Layer& D = plan->layers[L.src];
+                if (D.slot_partial >= 0) {      // pooled sums came with the depthwise output: fold the tiles, scale by 1/(H*W)
+                    ReduceArgs r{base[D.slot_partial], nullptr, nullptr, pool, N, D.pool_tiles, L.C, 1.f / (float)(L.H * L.W)};
+                    rc = launch_reduce(true, r, st);
+                } else {
+                    ReduceArgs r{xin, nullptr, nullptr, pool, N, L.H * L.W, L.C, 0.f};
+                    rc = launch_reduce(L.in_f32, r, st);
+                }
                 if (rc) break;
                 PwArgs a{};
                 a.x = pool; a.w = L.w_packed; a.se = nullptr;

@@ -117,21 +117,6 @@ def test_bn_calibrated_weights_f32(name, golden_dir, golden_x):
     assert np.abs(y - g["emb"]).max() <= 2e-3 * np.abs(g["emb"]).max()
 
 
-@pytest.mark.parametrize("name", ["mobilenetv3_large", "mobilenetv3_small", "mobilenetv2"])
-@pytest.mark.parametrize("precision", ["bf16", "f32"])
-def test_fused_expand_depthwise_equals_unfused(name, precision, golden_x):
-    """The expand->depthwise fusion keeps the expanded tensor in LDS; same MFMA order and rounding
-    points as the two separate kernels, so the embeddings must be bit-identical."""
-    m = product(name)
-    x = golden_x.to(DEV).repeat(5, 1, 1, 1)[:37]
-    with torch.no_grad():
-        a = m(x, precision=precision, fuse=True)
-        b = m(x, precision=precision, fuse=False)
-    assert m.plan(DEV, precision, True).lib.fr_plan_num_launches(m.plan(DEV, precision, True).handle) < \
-        m.plan(DEV, precision, False).lib.fr_plan_num_launches(m.plan(DEV, precision, False).handle)
-    assert torch.equal(a, b), (a - b).abs().max()
-
-
 def test_batch_sizes_and_determinism(golden_x):
     m = product("mobilenetv3_small")
     x = golden_x.to(DEV)
