@@ -33,30 +33,19 @@ struct DwGeom {          // derived launch geometry (host computed)
 
 template <int S> __host__ __device__ constexpr int dw_sw() { return S == 2 ? 2 : 4; }
 
+// Stage the input tile, the tap weights and bias/slopes of (image n, channel chunk cc, tile ty,tx)
+// into LDS by LDS-DMA and wait for them (block-wide).  LDS layout: tile [IH*IW][CBV] V8<T>, then
+// weights [K*K][2][CBV][4] fp32, then bias [2][CBV][4], then slopes [2][CBV][4].
 template <typename T, int K, int S>
-__global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int SW = dw_sw<S>();                  // outputs per work item (see dw_pick_tile)
-    constexpr int IWS = (SW - 1) * S + K;
+FR_DEV void dw_stage(const DwArgs& a, const DwGeom& g, unsigned char* smem, int n, int cc, int ty, int tx) {
     constexpr int UPE = sizeof(V8<T>) / 16;         // 16-byte units per 8-channel vector
-    const int CBV = a.CBV, CV = a.C >> 3;
-    const int cc = blockIdx.x % a.cchunks, tx = blockIdx.x / a.cchunks, ty = blockIdx.y;
-    const int n = g.n0 + blockIdx.z;
+    const int CBV = a.CBV, CV = a.C >> 3, IW = g.IW;
     const int cv0 = cc * CBV, ncv = min(CBV, CV - cv0);
-    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
-    const int IW = g.IW;
-
-    const V8<T>* tile = reinterpret_cast<const V8<T>*>(smem);            // [IH*IW][CBV]
     unsigned char* wl_b = smem + (size_t)g.IH * IW * CBV * sizeof(V8<T>);
-    const float* wl = reinterpret_cast<const float*>(wl_b);              // [K*K][2][CBV][4]
-    const float* bl = wl + K * K * CBV * 8;                              // [2][CBV][4] bias, then slopes
     const unsigned char* Xn = reinterpret_cast<const unsigned char*>(a.x) + (size_t)n * a.H * a.W * a.C * sizeof(T);
-    unsigned char* Yn = reinterpret_cast<unsigned char*>(a.y) + (size_t)n * a.Ho * a.Wo * a.C * sizeof(T);
     const unsigned char* Z = reinterpret_cast<const unsigned char*>(a.zeros);
-
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;
-    // ---- stage: input tile
+    const int gy0 = ty * a.TH * S - a.pad, gx0 = tx * a.TW * S - a.pad;
     for (int u0 = wave * 64; u0 < g.nunits; u0 += 256) {
         const int u = u0 + lane;
         if (u < g.nunits) {
@@ -70,7 +59,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
             __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + u0 * 16), 16, 0, 0);
         }
     }
-    // ---- stage: tap weights, unit (tap, half, cv) = 4 floats w[tap][(cv0+cv)*8 + 4*half ..]
+    // tap weights, unit (tap, half, cv) = 4 floats w[tap][(cv0+cv)*8 + 4*half ..]
     const int nw = K * K * 2 * CBV;
     for (int u0 = wave * 64; u0 < nw; u0 += 256) {
         const int u = u0 + lane;
@@ -80,7 +69,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
             __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(wl_b + u0 * 16), 16, 0, 0);
         }
     }
-    // ---- stage: bias [2][CBV][4], then slopes [2][CBV][4]   (4*CBV <= 64 lanes)
+    // bias [2][CBV][4], then slopes [2][CBV][4]   (4*CBV <= 64 lanes)
     if (wave == 0 && lane < 4 * CBV) {
         const int nb = 2 * CBV;
         const int which = lane >= nb, r = lane - which * nb;
@@ -91,72 +80,103 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+}
 
-    // ---- compute.  item(): one strip of SW outputs x 8 channels; psum receives the sum of the valid,
-    // activated outputs (squeeze-excite pooling) when a.pool is set.
+// One work item: SW horizontally adjacent outputs (row oy, strip sx of the tile) x channel vector cv,
+// bias included, activation applied.  out[o] = activated fp32 outputs.
+template <typename T, int K, int S>
+FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const float* bl, int IW,
+                    unsigned cv, unsigned oy, unsigned sx, Vec8f (&out)[dw_sw<S>()]) {
+    constexpr int SW = dw_sw<S>();
+    constexpr int IWS = (SW - 1) * S + K;
+    const int CBV = a.CBV;
+    float acc[SW][8];
+    {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl + (0 * CBV + cv) * 4);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(bl + (1 * CBV + cv) * 4);
+#pragma unroll
+        for (int o = 0; o < SW; ++o)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[o][j] = b0[j]; acc[o][4 + j] = b1[j]; }
+    }
+    const V8<T>* row = tile + ((oy * S) * IW + sx * SW * S) * CBV + cv;
+    const float* wrow = wl + cv * 4;
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+        float wr[K][8];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow + (kx * 2 + 0) * CBV * 4);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wrow + (kx * 2 + 1) * CBV * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wr[kx][j] = w0[j]; wr[kx][4 + j] = w1[j]; }
+        }
+#pragma unroll
+        for (int ix = 0; ix < IWS; ++ix) {
+            const Vec8f v = load8(reinterpret_cast<const T*>(row + ix * CBV));
+#pragma unroll
+            for (int o = 0; o < SW; ++o) {
+                const int kx = ix - o * S;
+                if (kx >= 0 && kx < K) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[o][j] = fmaf(v.v[j], wr[kx][j], acc[o][j]);
+                }
+            }
+        }
+        row += IW * CBV;
+        wrow += K * 2 * CBV * 4;
+    }
+    float sl[8];
+    if (a.act == FR_ACT_PRELU) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(bl + CBV * 8 + (0 * CBV + cv) * 4);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(bl + CBV * 8 + (1 * CBV + cv) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sl[j] = s0[j]; sl[4 + j] = s1[j]; }
+    }
+#pragma unroll
+    for (int o = 0; o < SW; ++o) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[o].v[j] = acc[o][j];
+        act8(out[o], a.act, sl);
+    }
+}
+
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int SW = dw_sw<S>();                  // outputs per work item (see dw_pick_tile)
+    const int CBV = a.CBV, CV = a.C >> 3;
+    const int cc = blockIdx.x % a.cchunks, tx = blockIdx.x / a.cchunks, ty = blockIdx.y;
+    const int n = g.n0 + blockIdx.z;
+    const int cv0 = cc * CBV, ncv = min(CBV, CV - cv0);
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int IW = g.IW;
+
+    const V8<T>* tile = reinterpret_cast<const V8<T>*>(smem);            // [IH*IW][CBV]
+    const float* wl = reinterpret_cast<const float*>(smem + (size_t)g.IH * IW * CBV * sizeof(V8<T>));
+    const float* bl = wl + K * K * CBV * 8;
+    unsigned char* Yn = reinterpret_cast<unsigned char*>(a.y) + (size_t)n * a.Ho * a.Wo * a.C * sizeof(T);
+    dw_stage<T, K, S>(a, g, smem, n, cc, ty, tx);
+
+    // psum receives the sum of the valid outputs (squeeze-excite pooling) when a.pool is set
     auto item = [&](int it, float* psum) {
         const unsigned r = div32(it, g.d_cbv), cv = it - r * CBV;
         const unsigned oy = div32(r, g.d_ns), sx = r - oy * g.nstrips;
         if ((int)cv >= ncv) return;
-        float acc[SW][8];
-        {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl + (0 * CBV + cv) * 4);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bl + (1 * CBV + cv) * 4);
-#pragma unroll
-            for (int o = 0; o < SW; ++o)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { acc[o][j] = b0[j]; acc[o][4 + j] = b1[j]; }
-        }
-        const V8<T>* row = tile + ((oy * S) * IW + sx * SW * S) * CBV + cv;
-        const float* wrow = wl + cv * 4;
-#pragma unroll 1
-        for (int ky = 0; ky < K; ++ky) {
-            float wr[K][8];
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow + (kx * 2 + 0) * CBV * 4);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wrow + (kx * 2 + 1) * CBV * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { wr[kx][j] = w0[j]; wr[kx][4 + j] = w1[j]; }
-            }
-#pragma unroll
-            for (int ix = 0; ix < IWS; ++ix) {
-                const Vec8f v = load8(reinterpret_cast<const T*>(row + ix * CBV));
-#pragma unroll
-                for (int o = 0; o < SW; ++o) {
-                    const int kx = ix - o * S;
-                    if (kx >= 0 && kx < K) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[o][j] = fmaf(v.v[j], wr[kx][j], acc[o][j]);
-                    }
-                }
-            }
-            row += IW * CBV;
-            wrow += K * 2 * CBV * 4;
-        }
+        Vec8f out[SW];
+        dw_item<T, K, S>(a, tile, wl, bl, IW, cv, oy, sx, out);
         const int gy = oy0 + (int)oy;
         if (gy < a.Ho) {
-            float sl[8];
-            if (a.act == FR_ACT_PRELU) {
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(bl + CBV * 8 + (0 * CBV + cv) * 4);
-                const f32x4 s1 = *reinterpret_cast<const f32x4*>(bl + CBV * 8 + (1 * CBV + cv) * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { sl[j] = s0[j]; sl[4 + j] = s1[j]; }
-            }
             const int gx0o = ox0 + (int)sx * SW;
             const int yoff = ((gy * a.Wo + gx0o) * a.C + (cv0 + (int)cv) * 8) * (int)sizeof(T);
 #pragma unroll
             for (int o = 0; o < SW; ++o) {
                 if (gx0o + o < a.Wo) {
-                    Vec8f v;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v.v[j] = acc[o][j];
-                    act8(v, a.act, sl);
                     if (psum) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) psum[j] += v.v[j];
+                        for (int j = 0; j < 8; ++j) psum[j] += out[o].v[j];
                     }
-                    store8(reinterpret_cast<T*>(Yn + yoff + o * a.C * (int)sizeof(T)), v);
+                    store8(reinterpret_cast<T*>(Yn + yoff + o * a.C * (int)sizeof(T)), out[o]);
                 }
             }
         }
