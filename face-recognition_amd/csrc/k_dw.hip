@@ -26,7 +26,7 @@ static inline Div32 make_div32(unsigned d) { Div32 r; r.d = d; r.mul = d > 1 ? (
 FR_DEV unsigned div32(unsigned n, Div32 v) { return v.d == 1 ? n : __umulhi(n, v.mul); }
 
 struct DwGeom {          // derived launch geometry (host computed)
-    Div32 d_cbv, d_iw, d_ns;
+    Div32 d_cbv, d_iw, d_ns, d_tw;
     int IH, IW, nstrips, nitems, nunits;
     int n0;              // first image of this launch slice (blockIdx.z is relative to it)
 };
@@ -297,4 +297,200 @@ int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st) {
     g.d_cbv = make_div32(a.CBV); g.d_iw = make_div32(g.IW); g.d_ns = make_div32(g.nstrips);
     if (a.pool && g.nitems > 512) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: pooled form needs <= 512 work items per tile");
     return f32 ? launch_dw_t<float>(k, stride, a, g, lds, st) : launch_dw_t<bf16>(k, stride, a, g, lds, st);
+}
+
+
+// ---- depthwise + following 1x1 conv in one kernel (bf16) -------------------------------------------
+// For the early blocks (all channels of a tile fit one block: C <= 128) the depthwise output never
+// goes to HBM: the block keeps its TH x TW x C result as bf16 in LDS (over the input tile, which is
+// dead by then) and multiplies it by the 1x1 weights on MFMA right away -- the pointwise launch and
+// one write + one read of the expanded activation disappear.  Arithmetic is identical to the two
+// separate kernels (same bf16 rounding of the depthwise output, same k order in the MFMA), so the
+// fused and the unfused plan give bit-identical results.
+struct DwpArgs {
+    DwArgs dw;            // depthwise part (dw.y unused; CBV == C/8, cchunks == 1)
+    const bf16* wp;       // 1x1 weights packed [NT][KS][64][8]
+    EpiArgs e;            // 1x1 epilogue: bias, slopes, residual, y, cout, act
+    int KS, NT;
+    int npx, npx_pad;     // TH*TW and its round-up to 32
+    int pitch;            // bytes per row of the LDS depthwise result
+    int off_wp, off_stage;
+};
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwp_kernel(DwpArgs x, DwGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef bf16 T;
+    constexpr int SW = dw_sw<S>();
+    const DwArgs& a = x.dw;
+    const int CBV = a.CBV;
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    const int n = g.n0 + blockIdx.z;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int IW = g.IW;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+
+    // 1x1 weights: 1-KiB fragments by LDS-DMA (waited for inside dw_stage together with the tile)
+    for (int f = wave; f < x.NT * x.KS; f += 4)
+        __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)(reinterpret_cast<const u32x4*>(x.wp) + f * 64 + lane),
+                                         (dw_lds_ptr_t)(smem + x.off_wp + f * 1024), 16, 0, 0);
+    const V8<T>* tile = reinterpret_cast<const V8<T>*>(smem);
+    const float* wl = reinterpret_cast<const float*>(smem + (size_t)g.IH * IW * CBV * sizeof(V8<T>));
+    const float* bl = wl + K * K * CBV * 8;
+    dw_stage<T, K, S>(a, g, smem, n, 0, ty, tx);
+
+    // depthwise into registers (two passes at most), as bf16
+    u32x4 keep[2][SW];
+    unsigned kpx[2], kcv[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int it = threadIdx.x + 256 * ps;
+        kpx[ps] = 0xffffffffu;
+        if (it < g.nitems) {
+            const unsigned r = div32(it, g.d_cbv), cv = it - r * CBV;
+            const unsigned oy = div32(r, g.d_ns), sx = r - oy * g.nstrips;
+            Vec8f out[SW];
+            dw_item<T, K, S>(a, tile, wl, bl, IW, cv, oy, sx, out);
+#pragma unroll
+            for (int o = 0; o < SW; ++o)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) keep[ps][o][i] = pack2bf(out[o].v[2 * i], out[o].v[2 * i + 1]);
+            kpx[ps] = oy * a.TW + sx * SW;
+            kcv[ps] = cv;
+        }
+    }
+    __syncthreads();                                   // the input tile is dead: its LDS becomes the depthwise result
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+        if (kpx[ps] != 0xffffffffu) {
+#pragma unroll
+            for (int o = 0; o < SW; ++o)
+                *reinterpret_cast<u32x4*>(smem + (kpx[ps] + o) * x.pitch + kcv[ps] * 16) = keep[ps][o];
+        }
+    __syncthreads();
+
+    // 1x1 conv on MFMA: D[cout][pixel] = W . dwo^T, 32 pixels per wave step
+    const int p = lane & 31, h = lane >> 5;
+    constexpr int SG = 2;
+    constexpr int PITCH = stage_pitch(SG * 64);
+    unsigned char* stage = smem + x.off_stage + wave * 32 * PITCH;
+    const bf16x8* wf = reinterpret_cast<const bf16x8*>(smem + x.off_wp) + lane;
+    const int cout = x.e.cout;
+    for (int rt = wave; rt * 32 < x.npx_pad; rt += 4) {
+        const int px = rt * 32 + p;
+        const unsigned oy = div32(px, g.d_tw), ox = px - oy * a.TW;
+        const int gy = oy0 + (int)oy, gx = ox0 + (int)ox;
+        const bool ok = px < x.npx && gy < a.Ho && gx < a.Wo;
+        const long m = ((long)n * a.Ho + gy) * a.Wo + gx;
+        bf16x8 xf[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int kk = 16 * s + 8 * h;
+            xf[s] = (s < x.KS && kk < a.C) ? *reinterpret_cast<const bf16x8*>(smem + px * x.pitch + kk * 2)
+                                           : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        for (int tg = 0; tg < x.NT; tg += SG) {
+#pragma unroll
+            for (int tt = 0; tt < SG; ++tt) {
+                const int t = tg + tt;
+                if (t < x.NT) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s)
+                        if (s < x.KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(t * x.KS + s) * 64], xf[s], acc, 0, 0, 0);
+                    epilogue_stage(acc, x.e, m, 32 * t + 16 * h, ok, stage, PITCH, p, 32 * tt + 16 * h);
+                }
+            }
+            // write the staged [32 pixels][<= 64 channels] back: consecutive pixels of a tile row are contiguous
+            const int ncol = min(SG * 32, cout - tg * 32), cr = ncol >> 3;
+            const unsigned magic = (65536u + cr - 1) / cr;
+            __builtin_amdgcn_wave_barrier();
+            for (int c = lane; c < 32 * cr; c += 64) {
+                const int q = (int)(((unsigned)c * magic) >> 16), ch = c - q * cr;
+                const int qpx = rt * 32 + q;
+                const unsigned qy = div32(qpx, g.d_tw), qx = qpx - qy * a.TW;
+                const int y = oy0 + (int)qy, xx = ox0 + (int)qx;
+                if (qpx < x.npx && y < a.Ho && xx < a.Wo) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(stage + q * PITCH + ch * 16);
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(x.e.y) + (((long)n * a.Ho + y) * a.Wo + xx) * cout + tg * 32 + ch * 8) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+struct DwpPlan { int TH, TW; size_t lds; int off_wp, off_stage, npx_pad, pitch; };
+
+// Tile for the fused form: all channels in one block, <= 512 work items, everything within 64 KB of LDS.
+static bool dwp_pick(int k, int s, int C, int Ho, int Wo, int cout, DwpPlan* out) {
+    const int CV = C / 8, sw = s == 2 ? 2 : 4;
+    if (C % 8 || CV > 16 || C > 128 || cout % 8 || cout > 128 || (k != 3 && k != 5) || (s != 1 && s != 2)) return false;
+    const int KS = cdiv(C, 16), NT = cdiv(cout, 32);
+    // row pitch of the LDS depthwise result: an odd number of 16-byte slots keeps the b128 fragment reads of
+    // 8 consecutive rows on distinct bank groups
+    const int pitch = C * 2 + ((CV & 1) ? 32 : 16);
+    double best = 1e30; bool found = false;
+    const int ths[] = {4, 7, 8, 14, 16};
+    const int tws[] = {4, 8, 16, 28, 32, 56};
+    for (int th : ths) for (int tw : tws) {
+        if (th - Ho >= 2 || tw - Wo >= 4) continue;
+        const int items = th * (tw / sw) * CV;
+        if (items > 512) continue;
+        const size_t tile = dw_lds_bytes(false, k, s, th, tw, CV);            // tile + taps + bias
+        const int npx_pad = cdiv(th * tw, 32) * 32;
+        const size_t dwo = (size_t)npx_pad * pitch;
+        // the output staging tiles live behind the depthwise result, inside the (by then dead) input tile
+        const size_t off_stage = align_up(dwo, 16);
+        const size_t off_wp = align_up(std::max(tile, off_stage + 4 * 32 * (size_t)stage_pitch(2 * 64)), 1024);
+        const size_t lds = off_wp + (size_t)NT * KS * 1024;
+        if (lds > 64 * 1024) continue;
+        const double IH = (th - 1) * s + k, IW = (tw - 1) * s + k;
+        const double useful = (double)std::min(th, Ho) * std::min(tw, Wo);
+        // staged input per useful output, padded MFMA rows, and a preference for >= 2 blocks per CU
+        double cost = (IH * IW) / useful + 0.5 * npx_pad / useful + (lds > 53 * 1024 ? 0.4 : lds > 40 * 1024 ? 0.2 : 0.0) + (items < 192 ? 0.5 : 0.0);
+        if (getenv("FR_DWP_DEBUG")) fprintf(stderr, "dwp cand k%d s%d C%d %dx%d: th %d tw %d items %d lds %zu cost %.3f\n", k, s, C, Ho, Wo, th, tw, items, lds, cost);
+        cost *= (double)cdiv(Ho, th) * th * cdiv(Wo, tw) * tw / ((double)Ho * Wo);   // edge waste
+        if (cost < best) {
+            best = cost; found = true;
+            *out = DwpPlan{th, tw, lds, (int)off_wp, (int)off_stage, npx_pad, pitch};
+        }
+    }
+    return found;
+}
+
+bool dwp_supported(int k, int stride, int C, int Ho, int Wo, int cout) {
+    DwpPlan pl;
+    return dwp_pick(k, stride, C, Ho, Wo, cout, &pl);
+}
+
+int launch_dwp(int k, int stride, DwArgs a, const bf16* wp, const EpiArgs& e, hipStream_t st) {
+    DwpPlan pl;
+    if (!a.zeros || a.N <= 0 || !dwp_pick(k, stride, a.C, a.Ho, a.Wo, e.cout, &pl)) FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: shape not supported");
+    if ((long)a.H * a.W * a.C * 4 >= 0x7FFFFFFFL) FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: image above 2 GB");
+    a.TH = pl.TH; a.TW = pl.TW; a.CBV = a.C / 8; a.cchunks = 1;
+    a.tiles_y = cdiv(a.Ho, a.TH); a.tiles_x = cdiv(a.Wo, a.TW);
+    a.pool = nullptr;
+    if (a.tiles_y > 65535) FR_FAIL(FR_ERR_ARG, "dw+1x1: grid too large");
+    DwGeom g{};
+    const int sw = stride == 2 ? 2 : 4;
+    g.IH = (a.TH - 1) * stride + k; g.IW = (a.TW - 1) * stride + k;
+    g.nstrips = a.TW / sw;
+    g.nitems = a.TH * g.nstrips * a.CBV;
+    g.nunits = g.IH * g.IW * a.CBV;
+    g.d_cbv = make_div32(a.CBV); g.d_iw = make_div32(g.IW); g.d_ns = make_div32(g.nstrips); g.d_tw = make_div32(a.TW);
+    DwpArgs x{};
+    x.dw = a; x.wp = wp; x.e = e; x.KS = cdiv(a.C, 16); x.NT = cdiv(e.cout, 32);
+    x.npx = a.TH * a.TW; x.npx_pad = pl.npx_pad; x.pitch = pl.pitch; x.off_wp = pl.off_wp; x.off_stage = pl.off_stage;
+    for (int n0 = 0; n0 < a.N; n0 += 65535) {
+        g.n0 = n0;
+        dim3 grid((unsigned)a.tiles_x, (unsigned)a.tiles_y, (unsigned)std::min(65535, a.N - n0));
+#define FR_DWP_CASE(KK, SS) if (k == KK && stride == SS) { hipLaunchKernelGGL((dwp_kernel<KK, SS>), grid, dim3(256), pl.lds, st, x, g); }
+        FR_DWP_CASE(3, 1) else FR_DWP_CASE(3, 2) else FR_DWP_CASE(5, 1) else FR_DWP_CASE(5, 2)
+#undef FR_DWP_CASE
+        FR_LAUNCH_CHECK("dwp_kernel");
+    }
+    return FR_OK;
 }

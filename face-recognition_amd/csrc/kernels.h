@@ -35,6 +35,9 @@ struct DwArgs {
     float* pool;          // optional [N][pool_tiles][C] per-tile channel sums of the OUTPUT (squeeze-excite pooling), or NULL
     int pool_tiles;       // tiles per image the caller sized `pool` for (must equal dw_tiles_per_image)
 };
+// Depthwise + the following 1x1 conv in one kernel (bf16; all channels of a tile in one block).
+bool dwp_supported(int k, int stride, int C, int Ho, int Wo, int cout);
+int launch_dwp(int k, int stride, DwArgs a, const bf16* w_pw_packed, const EpiArgs& pw_epilogue, hipStream_t st);
 // Spatial tiles per image launch_dw will use for this layer shape (sizes DwArgs::pool).
 int dw_tiles_per_image(bool f32, int k, int stride, int C, int Ho, int Wo);
 int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st);

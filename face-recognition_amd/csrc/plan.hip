@@ -355,9 +355,20 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         if (L.residual == -1 && false) {}
     }
     last_use[n - 1] = n;   // final output stays live
-    // (An expand(1x1)->depthwise fused kernel existed in round 1: bit-identical but slower than the two
-    // launches, so it was removed; FR_PLAN_NO_FUSE is still accepted and has no effect.)
-    (void)no_fuse;
+    // depthwise -> 1x1 fusion (bf16, C <= 128): the depthwise output stays in LDS (k_dw.hip, dwp_kernel).
+    // (An expand(1x1)->depthwise fused kernel also existed in round 1: bit-identical but slower than the
+    // two launches, so it was removed.)
+    for (int i = 0; !no_fuse && i + 1 < n; ++i) {
+        Layer& D = pl->layers[i];
+        Layer& P = pl->layers[i + 1];
+        if (D.kind == K_DW && !D.in_f32 && P.kind == K_PW && P.src == i && last_use[i] == i + 1 && !P.out_f32 &&
+            dwp_supported(D.k, D.stride, D.C, D.H, D.W, P.cout)) {
+            D.fused_next = true;
+            P.fuse_src = i;
+            if (D.src >= 0) last_use[D.src] = std::max(last_use[D.src], i + 1);
+            else if (need_input_copy) input_last_use = std::max(input_last_use, i + 1);
+        }
+    }
     std::vector<size_t>& sizes = pl->slot_bytes;
     std::vector<char> busy;
     if (need_input_copy) pl->input_slot = alloc_slot(sizes, busy, (size_t)in_c * in_h * in_w * pl->act_bytes());
@@ -497,6 +508,16 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
                 break;
             }
             case K_PW: case K_LINEAR: {
+                if (L.kind == K_PW && L.fuse_src >= 0) {            // depthwise + this 1x1 conv in one kernel
+                    const Layer& D = plan->layers[L.fuse_src];
+                    DwArgs a{};
+                    a.x = D.src < 0 ? in_nhwc : (const void*)base[plan->layers[D.src].slot];
+                    a.w = D.w_f32; a.bias = D.bias; a.slope = D.slope; a.y = nullptr;
+                    a.N = N; a.H = D.inH; a.W = D.inW; a.C = D.C; a.Ho = D.H; a.Wo = D.W; a.pad = D.pad; a.act = D.act;
+                    a.zeros = plan->zeros;
+                    rc = launch_dwp(D.k, D.stride, a, L.w_packed, EpiArgs{L.bias, L.slope, res, y, L.cout, L.act}, st);
+                    break;
+                }
                 if (L.via_conv) {
                     ConvArgs a{};
                     a.x = xin; a.w = L.w_packed;
@@ -603,7 +624,11 @@ extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char**
                                   "fc_kernel", "conv_glds_kernel"};
     const Layer& L = plan->layers[layer];
     *name = names[L.kind];
-    if (L.kind == K_PW) {
+    if (L.fused_next) {
+        *name = "(fused into the next layer)";
+    } else if (L.kind == K_PW && L.fuse_src >= 0) {
+        *name = "dwp_kernel";
+    } else if (L.kind == K_PW) {
         const bool se = L.src >= 0 && plan->layers[L.src].kind == K_SE;
         *name = pw_kernel_name(L.in_f32, L.out_f32, L.K, L.cout, se, L.H * L.W);
     } else if (L.kind == K_CONV3 && L.in_f32) {

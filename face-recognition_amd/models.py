@@ -31,9 +31,10 @@ def default_precision() -> str:
 
 
 def default_fuse() -> bool:
-    """Expand->depthwise fusion (k_xdw.hip) is correct (bit-identical) but currently slower than the
-    two separate kernels on MI355X, so it is opt-in: env FR_FUSE=1."""
-    return os.environ.get("FR_FUSE", "0") == "1"
+    """Cross-layer fusion (depthwise + following 1x1 conv in one kernel, k_dw.hip:dwp_kernel) is
+    bit-identical to the separate kernels and on by default; env FR_FUSE=0 turns it off.
+    ``forward_tap`` always uses an unfused plan so that every layer output exists."""
+    return os.environ.get("FR_FUSE", "1") != "0"
 
 
 def _make_divisible(v: float, divisor: int = 8) -> int:

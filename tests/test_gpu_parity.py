@@ -117,6 +117,20 @@ def test_bn_calibrated_weights_f32(name, golden_dir, golden_x):
     assert np.abs(y - g["emb"]).max() <= 2e-3 * np.abs(g["emb"]).max()
 
 
+@pytest.mark.parametrize("name", ["mobilenetv3_large", "mobilenetv3_small", "mobilenetv2", "mobilenetv1"])
+def test_fused_depthwise_pointwise_equals_unfused(name, golden_x):
+    """dwp_kernel (depthwise + following 1x1 conv, depthwise result kept in LDS) rounds and accumulates
+    exactly like the two separate kernels: fused and unfused plans must agree bit for bit."""
+    m = product(name)
+    x = golden_x.to(DEV)
+    with torch.no_grad():
+        a = m(x, precision="bf16", fuse=True)
+        b = m(x, precision="bf16", fuse=False)
+    assert torch.equal(a, b)
+    names = [m.plan(DEV, "bf16", True).profile(x)[i][1] for i in range(len(m.layer_names()))]
+    assert "dwp_kernel" in names
+
+
 def test_batch_sizes_and_determinism(golden_x):
     m = product("mobilenetv3_small")
     x = golden_x.to(DEV)
