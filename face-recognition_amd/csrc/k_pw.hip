@@ -535,7 +535,12 @@ static int launch_pw_stream_sg(const PwArgs& a, hipStream_t st) {
     const int mt = a.KS <= 2 ? 4 : (a.KS <= 4 ? 2 : (a.KS <= 8 ? 1 : 0));
     const long per_iter = 128L * (mt ? mt : 1);
     const long n_iter = (a.M + per_iter - 1) / per_iter;
-    const PwGrid pg{(int)std::min<long>(n_iter, 2048), cdiv(a.NT, NTB)};
+    // ~2048 blocks in total: with many column groups each block walks several pixel tiles, so that the
+    // weight slab it staged is amortised (one 128-pixel tile per block re-staged 20 KB of weights for
+    // 16 KB of activations in the 160->960 layers)
+    const int ng = cdiv(a.NT, NTB);
+    const long want = std::max<long>(8, cdiv(2048, ng));
+    const PwGrid pg{(int)std::min<long>(n_iter, want), ng};
     dim3 grid(pw_grid_blocks(pg.gx, pg.ng));
     size_t lds = (size_t)NTB * a.KS * 1024 + (size_t)NTB * 256;
     if (std::is_same<TOut, bf16>::value) lds += 4 * 32 * (size_t)stage_pitch(SG * 64);
