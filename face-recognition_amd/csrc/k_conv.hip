@@ -80,9 +80,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
             for (int i = 0; i < (SPLIT ? 4 : 2); ++i) pb[i] = u32x4{0, 0, 0, 0};
         }
         cur_w += W_SLICE;
-        if (++cur_chunk == chunks) {
-            cur_chunk = 0; ++cur_tap;
-            if (++cur_kx == a.ksize) { cur_kx = 0; ++cur_ky; }
+        ++cur_tap;                                         // tap inner, channel chunk outer (see pack_conv_weights)
+        if (++cur_kx == a.ksize) {
+            cur_kx = 0;
+            if (++cur_ky == a.ksize) { cur_ky = 0; cur_tap = 0; ++cur_chunk; }
         }
     };
     auto commit = [&](int buf) {
@@ -251,9 +252,10 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvArgs a) {
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + A_BYTES + (wave + 4 * j) * 1024), 16, 0, 0);
         }
         cur_w += (long)BN * ROWB;
-        if (++cur_chunk == chunks) {
-            cur_chunk = 0; ++cur_tap;
-            if (++cur_kx == a.ksize) { cur_kx = 0; ++cur_ky; }
+        ++cur_tap;                                         // tap inner, channel chunk outer (see pack_conv_weights)
+        if (++cur_kx == a.ksize) {
+            cur_kx = 0;
+            if (++cur_ky == a.ksize) { cur_ky = 0; cur_tap = 0; ++cur_chunk; }
         }
     };
 

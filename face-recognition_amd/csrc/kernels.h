@@ -57,7 +57,7 @@ int launch_stem(bool out_f32, const StemArgs& a, hipStream_t st);
 // ---- dense KxK conv (K = 3) / large-K linear (K = 1) as MFMA implicit GEMM
 struct ConvArgs {
     const void* x;        // [N,H,W,Cin] activations
-    const bf16* w;        // packed [cout tile][ks][NS][BN][32], ks = tap * (Cin/32) + chunk
+    const bf16* w;        // packed [cout tile][ks][NS][BN][32], ks = chunk * taps + tap (chunk = bk input channels)
     EpiArgs e;
     long M;               // N*Ho*Wo
     int H, W, Ho, Wo, Cin, ksize, stride, pad;

@@ -131,7 +131,10 @@ void pack_conv_weights(F&& wfn, int cout, int cin, int taps, int ns, int bk, std
     out.assign((size_t)ntiles * KS * ns * bn * bk, 0);
     for (int nt = 0; nt < ntiles; ++nt)
         for (int ks = 0; ks < KS; ++ks) {
-            const int tap = ks / chunks, c0 = (ks % chunks) * bk;
+            // K order: channel chunk outer, tap inner -- the 9 taps of one 64-channel chunk re-read the same
+            // 128-byte pixel segments in consecutive K slices, which keeps them in L2 (tap-outer order had the
+            // per-XCD footprint above the 4 MB L2: 74 % hit rate on the 256-channel SphereFace layers)
+            const int tap = ks % taps, c0 = (ks / taps) * bk;
             for (int r = 0; r < bn; ++r) {
                 const int co = nt * bn + (r / 32) * 32 + mfma_row_to_cout(r % 32);
                 if (co >= cout) continue;
