@@ -115,13 +115,13 @@ def bench_search(dev, rank, world, steps, warmup, n_gallery, n_queries):
 
 
 def sync(dev, world):
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
 
 
 def max_over_ranks(v, dev, world):
-    if world == 1:
+    if not torch.distributed.is_initialized():
         return v
     t = torch.tensor([v], dtype=torch.float64, device=dev)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -142,13 +142,15 @@ def main():
                     help="1:N gallery rows in total (default: 10M on one GPU = BASELINE.json configs[3]; 100M sharded over the ranks = configs[4])")
     ap.add_argument("--queries", type=int, default=65536)
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
+    ap.add_argument("--no-layer-profile", action="store_true", help="skip the per-layer event profile (roofline omitted)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    dist_on = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ        # under torchrun even a single rank goes through RCCL
+    if dist_on:
         torch.distributed.init_process_group("nccl", device_id=dev)
     import face_recognition_amd as fr
 
@@ -156,6 +158,20 @@ def main():
     model = fr.get_network(a.model).to(dev).eval()
     model.precision = a.precision
     x = synthetic_batch(a.batch, dev)
+    ms_layer = rows = plan = None
+    if rank == 0 and not a.no_layer_profile:
+        # ---- per-layer HIP-event timing on the launch stream (5 profiled passes, averaged); runs before the
+        # warm-up, outside the timed region
+        plan = model.plan(dev)
+        g = fr.models._Graph(); model.lower(g)
+        plan.descs_cio = [(int(d.cin), int(d.cout)) for d in g.descs]
+        plan.descs_ck = [(int(d.cin), int(d.cout), int(d.kernel), max(1, int(d.groups))) for d in g.descs]
+        reps = 5
+        acc = None
+        for _ in range(reps):
+            rows = plan.profile(x)
+            acc = [r[2] for r in rows] if acc is None else [p + r[2] for p, r in zip(acc, rows)]
+        ms_layer = [v / reps for v in acc]
     with torch.no_grad():
         for _ in range(a.warmup):
             y = model(x)
@@ -177,24 +193,18 @@ def main():
                                    f"random-init weights ({cfg_name})",
                        "global_batch": a.batch * world, "parallelism": f"replicas x{world} (no collective)"}}
 
-    if rank == 0:
-        # ---- per-layer HIP-event timing on the launch stream (5 profiled passes, averaged)
-        plan = model.plan(dev)
-        g = fr.models._Graph(); model.lower(g)
-        plan.descs_cio = [(int(d.cin), int(d.cout)) for d in g.descs]
-        plan.descs_ck = [(int(d.cin), int(d.cout), int(d.kernel), max(1, int(d.groups))) for d in g.descs]
-        reps = 5
-        acc = None
-        for _ in range(reps):
-            rows = plan.profile(x)
-            acc = [r[2] for r in rows] if acc is None else [p + r[2] for p, r in zip(acc, rows)]
-        ms_layer = [v / reps for v in acc]
+    if rank == 0 and ms_layer is not None:
         alg = layer_alg_bytes(plan, a.batch)
         flp = layer_alg_flops(plan, a.batch)
         fam = {}
+        carry_b = carry_f = 0.0
         for (name, kern, _, _), t, b, fl in zip(rows, ms_layer, alg, flp):
+            if kern.startswith("(fused"):          # computed inside the next layer's kernel: its work counts there
+                carry_b += b; carry_f += fl
+                continue
             f = fam.setdefault(kern, [0.0, 0.0, 0, 0.0])
-            f[0] += t; f[1] += b; f[2] += 1; f[3] += fl
+            f[0] += t; f[1] += b + carry_b; f[2] += 1; f[3] += fl + carry_f
+            carry_b = carry_f = 0.0
         dom = max(fam, key=lambda k: fam[k][0])
         t_dom, b_dom, n_dom, f_dom = fam[dom]
         # arithmetic intensity of the dominant family against the machine balance decides the bound
@@ -210,6 +220,12 @@ def main():
                                 "avg_launch_ms": round(t_dom / n_dom, 4), "alg_bytes_per_launch": int(b_dom / n_dom),
                                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        tf = os.path.join(ROOT, "profiles", f"hbm_traffic_{a.model}_b{a.batch}.json")
+        if os.path.exists(tf):          # HBM bytes per launch from a separate rocprofv3 --pmc run (tools/hbm_traffic.py)
+            k = json.load(open(tf)).get("kernels", {}).get(dom)
+            if k:
+                line["roofline"]["traffic"] = int(k["hbm_bytes_per_step"] / n_dom)
+                line["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
         if a.model in ALG_MB_PER_IMG:
             whole = ALG_MB_PER_IMG[a.model] * 1e6 * a.batch / (ms * 1e-3) / 1e9
             line["whole_path"] = {"bound": "hbm", "alg_MB_per_image": ALG_MB_PER_IMG[a.model], "achieved": round(whole, 1),
@@ -232,7 +248,7 @@ def main():
         line["cpu_baseline"] = cpu_baseline(a.model)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

@@ -123,7 +123,8 @@ class ShardedMatcher:
 
     def search(self, q: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         s, i = self.local.search(q)
-        if self.world == 1:
+        import torch.distributed as dist
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             return s, i
         gs, gi = all_gather_topk(s, i, self.group)
         return merge_topk(gs, gi, self.k)
