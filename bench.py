@@ -168,6 +168,8 @@ def main():
         plan.descs_ck = [(int(d.cin), int(d.cout), int(d.kernel), max(1, int(d.groups))) for d in g.descs]
         reps = 5
         acc = None
+        for _ in range(3):                       # untimed: clocks and caches warm before the averaged passes
+            plan.profile(x)
         for _ in range(reps):
             rows = plan.profile(x)
             acc = [r[2] for r in rows] if acc is None else [p + r[2] for p, r in zip(acc, rows)]

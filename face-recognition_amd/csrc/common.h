@@ -90,6 +90,13 @@ FR_DEV float apply_act(float v, int act, float slope) {
     }
 }
 
+// max(v, 0) as the single v_max_f32 it is (fmaxf also emits a canonicalising v_max v,v,v in front).
+FR_DEV float relu1(float v) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 // Activation of 8 channels with ONE uniform branch per vector (apply_act per element makes the
 // compiler emit a switch per element).
 FR_DEV void act8(Vec8f& v, int act, const float* slope8) {
@@ -101,7 +108,7 @@ FR_DEV void act8(Vec8f& v, int act, const float* slope8) {
         for (int j = 0; j < 8; ++j) v.v[j] = v.v[j] * fminf(fmaxf(v.v[j] + 3.f, 0.f), 6.f) * (1.f / 6.f);
     } else if (act == FR_ACT_RELU) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v.v[j] = fmaxf(v.v[j], 0.f);
+        for (int j = 0; j < 8; ++j) v.v[j] = relu1(v.v[j]);
     } else if (act == FR_ACT_HSIGMOID) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v.v[j] = fminf(fmaxf(v.v[j] + 3.f, 0.f), 6.f) * (1.f / 6.f);

@@ -28,6 +28,7 @@ FR_DEV unsigned div32(unsigned n, Div32 v) { return v.d == 1 ? n : __umulhi(n, v
 struct DwGeom {          // derived launch geometry (host computed)
     Div32 d_cbv, d_iw, d_ns, d_tw;
     int IH, IW, nstrips, nitems, nunits;
+    int PP;              // LDS pitch of one tile pixel in 8-channel vectors (CBV, or CBV+1 when the tile is computed in the kernel)
     int n0;              // first image of this launch slice (blockIdx.z is relative to it)
 };
 
@@ -36,17 +37,17 @@ template <int S> __host__ __device__ constexpr int dw_sw() { return S == 2 ? 2 :
 // Stage the input tile, the tap weights and bias/slopes of (image n, channel chunk cc, tile ty,tx)
 // into LDS by LDS-DMA and wait for them (block-wide).  LDS layout: tile [IH*IW][CBV] V8<T>, then
 // weights [K*K][2][CBV][4] fp32, then bias [2][CBV][4], then slopes [2][CBV][4].
-template <typename T, int K, int S>
+template <typename T, int K, int S, bool TILE = true>
 FR_DEV void dw_stage(const DwArgs& a, const DwGeom& g, unsigned char* smem, int n, int cc, int ty, int tx) {
     constexpr int UPE = sizeof(V8<T>) / 16;         // 16-byte units per 8-channel vector
     const int CBV = a.CBV, CV = a.C >> 3, IW = g.IW;
     const int cv0 = cc * CBV, ncv = min(CBV, CV - cv0);
-    unsigned char* wl_b = smem + (size_t)g.IH * IW * CBV * sizeof(V8<T>);
+    unsigned char* wl_b = smem + (size_t)g.IH * IW * g.PP * sizeof(V8<T>);
     const unsigned char* Xn = reinterpret_cast<const unsigned char*>(a.x) + (size_t)n * a.H * a.W * a.C * sizeof(T);
     const unsigned char* Z = reinterpret_cast<const unsigned char*>(a.zeros);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int gy0 = ty * a.TH * S - a.pad, gx0 = tx * a.TW * S - a.pad;
-    for (int u0 = wave * 64; u0 < g.nunits; u0 += 256) {
+    for (int u0 = wave * 64; TILE && u0 < g.nunits; u0 += 256) {
         const int u = u0 + lane;
         if (u < g.nunits) {
             const unsigned q = (unsigned)u / UPE;
@@ -85,7 +86,7 @@ FR_DEV void dw_stage(const DwArgs& a, const DwGeom& g, unsigned char* smem, int 
 // One work item: SW horizontally adjacent outputs (row oy, strip sx of the tile) x channel vector cv,
 // bias included, activation applied.  out[o] = activated fp32 outputs.
 template <typename T, int K, int S>
-FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const float* bl, int IW,
+FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const float* bl, int IW, int PP,
                     unsigned cv, unsigned oy, unsigned sx, Vec8f (&out)[dw_sw<S>()]) {
     constexpr int SW = dw_sw<S>();
     constexpr int IWS = (SW - 1) * S + K;
@@ -99,7 +100,7 @@ FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const f
 #pragma unroll
             for (int j = 0; j < 4; ++j) { acc[o][j] = b0[j]; acc[o][4 + j] = b1[j]; }
     }
-    const V8<T>* row = tile + ((oy * S) * IW + sx * SW * S) * CBV + cv;
+    const V8<T>* row = tile + ((oy * S) * IW + sx * SW * S) * PP + cv;
     const float* wrow = wl + cv * 4;
 #pragma unroll 1
     for (int ky = 0; ky < K; ++ky) {
@@ -113,7 +114,7 @@ FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const f
         }
 #pragma unroll
         for (int ix = 0; ix < IWS; ++ix) {
-            const Vec8f v = load8(reinterpret_cast<const T*>(row + ix * CBV));
+            const Vec8f v = load8(reinterpret_cast<const T*>(row + ix * PP));
 #pragma unroll
             for (int o = 0; o < SW; ++o) {
                 const int kx = ix - o * S;
@@ -123,7 +124,7 @@ FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const f
                 }
             }
         }
-        row += IW * CBV;
+        row += IW * PP;
         wrow += K * 2 * CBV * 4;
     }
     float sl[8];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
     const int IW = g.IW;
 
     const V8<T>* tile = reinterpret_cast<const V8<T>*>(smem);            // [IH*IW][CBV]
-    const float* wl = reinterpret_cast<const float*>(smem + (size_t)g.IH * IW * CBV * sizeof(V8<T>));
+    const float* wl = reinterpret_cast<const float*>(smem + (size_t)g.IH * IW * g.PP * sizeof(V8<T>));
     const float* bl = wl + K * K * CBV * 8;
     unsigned char* Yn = reinterpret_cast<unsigned char*>(a.y) + (size_t)n * a.Ho * a.Wo * a.C * sizeof(T);
     dw_stage<T, K, S>(a, g, smem, n, cc, ty, tx);
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
         const unsigned oy = div32(r, g.d_ns), sx = r - oy * g.nstrips;
         if ((int)cv >= ncv) return;
         Vec8f out[SW];
-        dw_item<T, K, S>(a, tile, wl, bl, IW, cv, oy, sx, out);
+        dw_item<T, K, S>(a, tile, wl, bl, IW, g.PP, cv, oy, sx, out);
         const int gy = oy0 + (int)oy;
         if (gy < a.Ho) {
             const int gx0o = ox0 + (int)sx * SW;
@@ -294,6 +295,7 @@ int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st) {
     g.nstrips = a.TW / sw;
     g.nitems = a.TH * g.nstrips * a.CBV;
     g.nunits = g.IH * g.IW * a.CBV * (f32 ? 2 : 1);
+    g.PP = a.CBV;
     g.d_cbv = make_div32(a.CBV); g.d_iw = make_div32(g.IW); g.d_ns = make_div32(g.nstrips);
     if (a.pool && g.nitems > 512) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: pooled form needs <= 512 work items per tile");
     return f32 ? launch_dw_t<float>(k, stride, a, g, lds, st) : launch_dw_t<bf16>(k, stride, a, g, lds, st);
@@ -315,10 +317,104 @@ struct DwpArgs {
     int npx, npx_pad;     // TH*TW and its round-up to 32
     int pitch;            // bytes per row of the LDS depthwise result
     int off_wp, off_stage;
+    // optional expand 1x1 conv in front (EXPAND form): dw.x is then unused
+    const bf16* xin;      // block input [N,H,W,Cin]
+    const bf16* we;       // expand weights packed [NTe][KSe][64][8]
+    const float* be;      // expand bias (padded to 32)
+    const float* se;      // expand PReLU slopes or NULL
+    int act_e, Cin, KSe, NTe;
+    int off_we, off_in;
+    Div32 d_cin8;
 };
 
-template <int K, int S>
-__global__ __launch_bounds__(256) void dwp_kernel(DwpArgs x, DwGeom g) {
+// Expand phase of the fused block: out[pixel][C] = act(W_e . in[pixel][Cin] + b) for every pixel of the staged
+// input tile, written as bf16 in the depthwise tile layout (pitch g.PP vectors per pixel), zero outside the
+// image.  The kernel is bound by instruction issue (one wave per SIMD and block, three blocks per CU), so
+// everything uniform is decided at compile time: k-steps, channel tiles, the activation (ACT < 0: run-time
+// act8) and whether the tile touches the image border at all (MASK).  Weights and bias live in registers.
+template <int KSE, int NTE, int ACT, bool MASK>
+FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, const float* bel, const float* sel,
+                       int gy0, int gx0, int wave, int lane) {
+    typedef short __attribute__((ext_vector_type(2))) s16x2;
+    const DwArgs& a = x.dw;
+    const int IW = g.IW, npin = g.IH * IW;
+    const int pe = lane & 31, he = lane >> 5;
+    const unsigned char* inl = smem + x.off_in;
+    const int rowb = x.Cin * 2;
+    u32x4* etile = reinterpret_cast<u32x4*>(smem);
+    bf16x8 wv[NTE][KSE];
+    f32x4 bb[NTE][4];
+    {
+        const bf16x8* wef = reinterpret_cast<const bf16x8*>(smem + x.off_we) + lane;
+#pragma unroll
+        for (int t = 0; t < NTE; ++t) {
+#pragma unroll
+            for (int sk = 0; sk < KSE; ++sk) wv[t][sk] = wef[(t * KSE + sk) * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bb[t][q] = *reinterpret_cast<const f32x4*>(bel + 32 * t + 16 * he + 4 * q);
+        }
+    }
+    for (int rt = wave; rt * 32 < npin; rt += 4) {
+        const int pix = rt * 32 + pe;
+        const int pc = pix < npin ? pix : npin - 1;
+        bool inimg = true;
+        if constexpr (MASK) {
+            const unsigned iy = div32(pc, g.d_iw), ix = pc - iy * IW;
+            const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
+            inimg = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        }
+        bf16x8 xf[KSE];
+#pragma unroll
+        for (int sk = 0; sk < KSE; ++sk) {
+            const int kk = 16 * sk + 8 * he;
+            xf[sk] = kk < x.Cin ? *reinterpret_cast<const bf16x8*>(inl + pc * rowb + kk * 2) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        u32x4* dst = etile + pix * g.PP + 2 * he;
+#pragma unroll
+        for (int t = 0; t < NTE; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int sk = 0; sk < KSE; ++sk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk], xf[sk], acc, 0, 0, 0);
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const int c = 32 * t + 16 * he + 8 * gg;
+                Vec8f v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v.v[i] = acc[8 * gg + i] + bb[t][2 * gg][i]; v.v[4 + i] = acc[8 * gg + 4 + i] + bb[t][2 * gg + 1][i]; }
+                u32x4 r;
+                if constexpr (ACT == FR_ACT_RELU) {
+                    // max(.,0) on the packed bf16 pairs: a negative float is a negative int16, so one
+                    // v_pk_max_i16 does two channels; same bits as rounding max(v, 0)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const s16x2 h = __builtin_bit_cast(s16x2, pack2bf(v.v[2 * i], v.v[2 * i + 1]));
+                        r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(h, s16x2{0, 0}));
+                    }
+                } else {
+                    if constexpr (ACT == FR_ACT_HSWISH) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v.v[j] = v.v[j] * fminf(fmaxf(v.v[j] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                    } else {
+                        act8(v, x.act_e, sel ? sel + c : nullptr);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] = pack2bf(v.v[2 * i], v.v[2 * i + 1]);
+                }
+                if constexpr (MASK) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] = inimg ? r[i] : 0u;
+                }
+                if (pix < npin && (t < NTE - 1 || c < a.C)) dst[4 * t + gg] = r;
+            }
+        }
+    }
+}
+
+template <int K, int S, int KSE, int NTE>
+__global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
+    constexpr bool EXPAND = KSE > 0;      // KSE, NTE: k-steps and 32-channel tiles of the expand conv (compile time)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef bf16 T;
     constexpr int SW = dw_sw<S>();
@@ -335,9 +431,56 @@ __global__ __launch_bounds__(256) void dwp_kernel(DwpArgs x, DwGeom g) {
         __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)(reinterpret_cast<const u32x4*>(x.wp) + f * 64 + lane),
                                          (dw_lds_ptr_t)(smem + x.off_wp + f * 1024), 16, 0, 0);
     const V8<T>* tile = reinterpret_cast<const V8<T>*>(smem);
-    const float* wl = reinterpret_cast<const float*>(smem + (size_t)g.IH * IW * CBV * sizeof(V8<T>));
+    const float* wl = reinterpret_cast<const float*>(smem + (size_t)g.IH * IW * g.PP * sizeof(V8<T>));
     const float* bl = wl + K * K * CBV * 8;
-    dw_stage<T, K, S>(a, g, smem, n, 0, ty, tx);
+    if constexpr (!EXPAND) {
+        dw_stage<T, K, S>(a, g, smem, n, 0, ty, tx);
+    } else {
+        // ---- expand 1x1 conv computed here: stage the (4x narrower) block input instead of the expanded
+        // tile, multiply it on MFMA and write the activated bf16 result in the depthwise tile layout;
+        // pixels outside the image are zero (the padding of the depthwise conv), not act(bias)
+        const int cin8 = x.Cin >> 3, npin = g.IH * IW;
+        const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;
+        const unsigned char* Xn = reinterpret_cast<const unsigned char*>(x.xin) + (size_t)n * a.H * a.W * x.Cin * 2;
+        const unsigned char* Z = reinterpret_cast<const unsigned char*>(a.zeros);
+        const int nin = npin * cin8;
+        for (int u0 = wave * 64; u0 < nin; u0 += 256) {
+            const int u = u0 + lane;
+            if (u < nin) {
+                const unsigned pix = div32(u, x.d_cin8), cv = u - pix * cin8;
+                const unsigned iy = div32(pix, g.d_iw), ix = pix - iy * IW;
+                const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
+                const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                const unsigned char* src = ok ? Xn + ((gy * a.W + gx) * x.Cin + (int)cv * 8) * 2 : Z;
+                __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + x.off_in + u0 * 16), 16, 0, 0);
+            }
+        }
+        for (int f = wave; f < NTE * KSE; f += 4)
+            __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)(reinterpret_cast<const u32x4*>(x.we) + f * 64 + lane),
+                                             (dw_lds_ptr_t)(smem + x.off_we + f * 1024), 16, 0, 0);
+        // expand bias and slopes: [NTe*32] floats each, behind the staged input
+        const int off_be = x.off_in + ((nin * 16 + 15) & ~15), nbe = NTE * 8;
+        if (wave == 1 && lane < 2 * nbe) {
+            const int which = lane >= nbe, ch = (lane - which * nbe) * 4;
+            const float* pb = which ? x.se : x.be;
+            const void* src = (pb && ch < a.C) ? (const void*)(pb + ch) : (const void*)Z;
+            __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + off_be), 16, 0, 0);
+        }
+        const float* bel = reinterpret_cast<const float*>(smem + off_be);
+        const float* sel = x.se ? bel + NTE * 32 : nullptr;
+        dw_stage<T, K, S, false>(a, g, smem, n, 0, ty, tx);               // taps + bias; waits for everything
+        const bool border = gy0 < 0 || gx0 < 0 || gy0 + g.IH > a.H || gx0 + IW > a.W;
+        if (x.act_e == FR_ACT_RELU) {
+            if (border) dwp_expand<KSE, NTE, FR_ACT_RELU, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            else dwp_expand<KSE, NTE, FR_ACT_RELU, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+        } else if (x.act_e == FR_ACT_HSWISH) {
+            if (border) dwp_expand<KSE, NTE, FR_ACT_HSWISH, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            else dwp_expand<KSE, NTE, FR_ACT_HSWISH, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+        } else {
+            dwp_expand<KSE, NTE, -1, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+        }
+        __syncthreads();
+    }
 
     // depthwise into registers (two passes at most), as bf16
     u32x4 keep[2][SW];
@@ -350,7 +493,7 @@ __global__ __launch_bounds__(256) void dwp_kernel(DwpArgs x, DwGeom g) {
             const unsigned r = div32(it, g.d_cbv), cv = it - r * CBV;
             const unsigned oy = div32(r, g.d_ns), sx = r - oy * g.nstrips;
             Vec8f out[SW];
-            dw_item<T, K, S>(a, tile, wl, bl, IW, cv, oy, sx, out);
+            dw_item<T, K, S>(a, tile, wl, bl, IW, g.PP, cv, oy, sx, out);
 #pragma unroll
             for (int o = 0; o < SW; ++o)
 #pragma unroll
@@ -422,13 +565,19 @@ __global__ __launch_bounds__(256) void dwp_kernel(DwpArgs x, DwGeom g) {
     }
 }
 
-struct DwpPlan { int TH, TW; size_t lds; int off_wp, off_stage, npx_pad, pitch; };
+struct DwpPlan { int TH, TW; size_t lds; int off_wp, off_stage, npx_pad, pitch, off_we, off_in; };
 
 // Tile for the fused form: all channels in one block, <= 512 work items, everything within 64 KB of LDS.
-static bool dwp_pick(int k, int s, int C, int Ho, int Wo, int cout, DwpPlan* out) {
+// cin > 0: the expand 1x1 conv (cin -> C) is computed in the kernel too.
+static bool dwp_pick(int k, int s, int C, int Ho, int Wo, int cout, int cin, DwpPlan* out) {
     const int CV = C / 8, sw = s == 2 ? 2 : 4;
     if (C % 8 || CV > 16 || C > 128 || cout % 8 || cout > 128 || (k != 3 && k != 5) || (s != 1 && s != 2)) return false;
+    if (cin) {        // expand form: 3x3 only, and only the (k-steps, channel tiles) shapes that are instantiated
+        const int kse = cdiv(cin, 16), nte = cdiv(C, 32);
+        if (cin % 8 || k != 3 || !((kse == 1 && (nte == 2 || nte == 3)) || (kse == 2 && nte == 3))) return false;
+    }
     const int KS = cdiv(C, 16), NT = cdiv(cout, 32);
+    const int KSe = cdiv(cin, 16), NTe = cdiv(C, 32);
     // row pitch of the LDS depthwise result: an odd number of 16-byte slots keeps the b128 fragment reads of
     // 8 consecutive rows on distinct bank groups
     const int pitch = C * 2 + ((CV & 1) ? 32 : 16);
@@ -439,36 +588,40 @@ static bool dwp_pick(int k, int s, int C, int Ho, int Wo, int cout, DwpPlan* out
         if (th - Ho >= 2 || tw - Wo >= 4) continue;
         const int items = th * (tw / sw) * CV;
         if (items > 512) continue;
-        const size_t tile = dw_lds_bytes(false, k, s, th, tw, CV);            // tile + taps + bias
         const int npx_pad = cdiv(th * tw, 32) * 32;
         const size_t dwo = (size_t)npx_pad * pitch;
+        const double IH = (th - 1) * s + k, IW = (tw - 1) * s + k;
+        // tile + taps + bias; a tile computed in the kernel has one spare 16-byte slot per pixel, so that the
+        // MFMA lanes (one pixel each) write it without bank conflicts
+        const size_t tile = dw_lds_bytes(false, k, s, th, tw, CV) + (cin ? (size_t)(IH * IW) * 16 : 0);
         // the output staging tiles live behind the depthwise result, inside the (by then dead) input tile
         const size_t off_stage = align_up(dwo, 16);
         const size_t off_wp = align_up(std::max(tile, off_stage + 4 * 32 * (size_t)stage_pitch(2 * 64)), 1024);
-        const size_t lds = off_wp + (size_t)NT * KS * 1024;
+        const size_t off_we = off_wp + (size_t)NT * KS * 1024;
+        const size_t off_in = off_we + (size_t)NTe * KSe * 1024;
+        const size_t lds = off_in + (cin ? align_up((size_t)(IH * IW) * cin * 2, 16) + (size_t)NTe * 256 : 0);
         if (lds > 64 * 1024) continue;
-        const double IH = (th - 1) * s + k, IW = (tw - 1) * s + k;
         const double useful = (double)std::min(th, Ho) * std::min(tw, Wo);
-        // staged input per useful output, padded MFMA rows, and a preference for >= 2 blocks per CU
+        // staged input per useful output, padded MFMA rows, and a preference for >= 3 blocks per CU
         double cost = (IH * IW) / useful + 0.5 * npx_pad / useful + (lds > 53 * 1024 ? 0.4 : lds > 40 * 1024 ? 0.2 : 0.0) + (items < 192 ? 0.5 : 0.0);
-        if (getenv("FR_DWP_DEBUG")) fprintf(stderr, "dwp cand k%d s%d C%d %dx%d: th %d tw %d items %d lds %zu cost %.3f\n", k, s, C, Ho, Wo, th, tw, items, lds, cost);
         cost *= (double)cdiv(Ho, th) * th * cdiv(Wo, tw) * tw / ((double)Ho * Wo);   // edge waste
         if (cost < best) {
             best = cost; found = true;
-            *out = DwpPlan{th, tw, lds, (int)off_wp, (int)off_stage, npx_pad, pitch};
+            *out = DwpPlan{th, tw, lds, (int)off_wp, (int)off_stage, npx_pad, pitch, (int)off_we, (int)off_in};
         }
     }
     return found;
 }
 
-bool dwp_supported(int k, int stride, int C, int Ho, int Wo, int cout) {
+bool dwp_supported(int k, int stride, int C, int Ho, int Wo, int cout, int cin) {
     DwpPlan pl;
-    return dwp_pick(k, stride, C, Ho, Wo, cout, &pl);
+    return dwp_pick(k, stride, C, Ho, Wo, cout, cin, &pl);
 }
 
-int launch_dwp(int k, int stride, DwArgs a, const bf16* wp, const EpiArgs& e, hipStream_t st) {
+int launch_dwp(int k, int stride, DwArgs a, const bf16* wp, const EpiArgs& e, const DwpExpand* ex, hipStream_t st) {
     DwpPlan pl;
-    if (!a.zeros || a.N <= 0 || !dwp_pick(k, stride, a.C, a.Ho, a.Wo, e.cout, &pl)) FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: shape not supported");
+    const int cin = ex ? ex->Cin : 0;
+    if (!a.zeros || a.N <= 0 || !dwp_pick(k, stride, a.C, a.Ho, a.Wo, e.cout, cin, &pl)) FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: shape not supported");
     if ((long)a.H * a.W * a.C * 4 >= 0x7FFFFFFFL) FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: image above 2 GB");
     a.TH = pl.TH; a.TW = pl.TW; a.CBV = a.C / 8; a.cchunks = 1;
     a.tiles_y = cdiv(a.Ho, a.TH); a.tiles_x = cdiv(a.Wo, a.TW);
@@ -480,16 +633,28 @@ int launch_dwp(int k, int stride, DwArgs a, const bf16* wp, const EpiArgs& e, hi
     g.nstrips = a.TW / sw;
     g.nitems = a.TH * g.nstrips * a.CBV;
     g.nunits = g.IH * g.IW * a.CBV;
+    g.PP = ex ? a.CBV + 1 : a.CBV;
     g.d_cbv = make_div32(a.CBV); g.d_iw = make_div32(g.IW); g.d_ns = make_div32(g.nstrips); g.d_tw = make_div32(a.TW);
     DwpArgs x{};
     x.dw = a; x.wp = wp; x.e = e; x.KS = cdiv(a.C, 16); x.NT = cdiv(e.cout, 32);
     x.npx = a.TH * a.TW; x.npx_pad = pl.npx_pad; x.pitch = pl.pitch; x.off_wp = pl.off_wp; x.off_stage = pl.off_stage;
+    if (ex) {
+        x.xin = ex->xin; x.we = ex->we; x.be = ex->bias; x.se = ex->slope; x.act_e = ex->act; x.Cin = ex->Cin;
+        x.KSe = cdiv(ex->Cin, 16); x.NTe = cdiv(a.C, 32); x.off_we = pl.off_we; x.off_in = pl.off_in;
+        x.d_cin8 = make_div32(ex->Cin / 8);
+    }
     for (int n0 = 0; n0 < a.N; n0 += 65535) {
         g.n0 = n0;
         dim3 grid((unsigned)a.tiles_x, (unsigned)a.tiles_y, (unsigned)std::min(65535, a.N - n0));
-#define FR_DWP_CASE(KK, SS) if (k == KK && stride == SS) { hipLaunchKernelGGL((dwp_kernel<KK, SS>), grid, dim3(256), pl.lds, st, x, g); }
+#define FR_DWP_CASE(KK, SS) if (!ex && k == KK && stride == SS) hipLaunchKernelGGL((dwp_kernel<KK, SS, 0, 0>), grid, dim3(256), pl.lds, st, x, g);
+#define FR_DWX_CASE(SS, KE, NE) if (ex && k == 3 && stride == SS && x.KSe == KE && x.NTe == NE) \
+        hipLaunchKernelGGL((dwp_kernel<3, SS, KE, NE>), grid, dim3(256), pl.lds, st, x, g);
         FR_DWP_CASE(3, 1) else FR_DWP_CASE(3, 2) else FR_DWP_CASE(5, 1) else FR_DWP_CASE(5, 2)
+        else FR_DWX_CASE(1, 1, 2) else FR_DWX_CASE(2, 1, 2) else FR_DWX_CASE(1, 1, 3) else FR_DWX_CASE(2, 1, 3)
+        else FR_DWX_CASE(1, 2, 3) else FR_DWX_CASE(2, 2, 3)
+        else FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: no kernel for this shape");
 #undef FR_DWP_CASE
+#undef FR_DWX_CASE
         FR_LAUNCH_CHECK("dwp_kernel");
     }
     return FR_OK;

@@ -40,7 +40,8 @@ struct Layer {
     int conv_bk = 32;                     // K-slice width the conv weights were packed with
     bool via_conv = false;                // Linear routed through the conv implicit-GEMM kernel
     bool fused_next = false;              // (reserved: a layer computed inside the next layer's kernel; none today)
-    int fuse_src = -1;
+    int fuse_src = -1;                    // 1x1 conv: index of the depthwise layer computed in its kernel (dwp_kernel)
+    int fuse_src2 = -1;                   // ... and of the expand 1x1 conv in front of that depthwise layer
 };
 
 }  // namespace
@@ -359,17 +360,31 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
     }
     last_use[n - 1] = n;   // final output stays live
     // depthwise -> 1x1 fusion (bf16, C <= 128): the depthwise output stays in LDS (k_dw.hip, dwp_kernel).
-    // (An expand(1x1)->depthwise fused kernel also existed in round 1: bit-identical but slower than the
-    // two launches, so it was removed.)
     for (int i = 0; !no_fuse && i + 1 < n; ++i) {
         Layer& D = pl->layers[i];
         Layer& P = pl->layers[i + 1];
         if (D.kind == K_DW && !D.in_f32 && P.kind == K_PW && P.src == i && last_use[i] == i + 1 && !P.out_f32 &&
-            dwp_supported(D.k, D.stride, D.C, D.H, D.W, P.cout)) {
+            dwp_supported(D.k, D.stride, D.C, D.H, D.W, P.cout, 0)) {
             D.fused_next = true;
             P.fuse_src = i;
+            const int e_last_use = D.src >= 0 ? last_use[D.src] : -1;      // before the fused kernel extends it
             if (D.src >= 0) last_use[D.src] = std::max(last_use[D.src], i + 1);
             else if (need_input_copy) input_last_use = std::max(input_last_use, i + 1);
+            // the expand 1x1 conv in front of the depthwise conv as well (expand -> depthwise -> project): bit-identical
+            // to the separate launches but, as measured in round 1, slower than them (two blocks per CU, the MFMA
+            // epilogue of the expand phase is latency-bound) -- opt-in with FR_FUSE3=1 until that is solved
+            const bool fuse3 = getenv("FR_FUSE3") && atoi(getenv("FR_FUSE3")) != 0;
+            if (fuse3 && D.src >= 0 && D.src == i - 1) {
+                Layer& E = pl->layers[i - 1];
+                const bool se_in = E.src >= 0 && pl->layers[E.src].kind == K_SE;
+                if (E.kind == K_PW && !E.in_f32 && !E.out_f32 && E.residual < 0 && !se_in && e_last_use == i && E.fuse_src < 0 &&
+                    dwp_supported(D.k, D.stride, D.C, D.H, D.W, P.cout, E.K)) {
+                    E.fused_next = true;
+                    P.fuse_src2 = i - 1;
+                    if (E.src >= 0) last_use[E.src] = std::max(last_use[E.src], i + 1);
+                    else if (need_input_copy) input_last_use = std::max(input_last_use, i + 1);
+                }
+            }
         }
     }
     std::vector<size_t>& sizes = pl->slot_bytes;
@@ -514,11 +529,18 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
                 if (L.kind == K_PW && L.fuse_src >= 0) {            // depthwise + this 1x1 conv in one kernel
                     const Layer& D = plan->layers[L.fuse_src];
                     DwArgs a{};
-                    a.x = D.src < 0 ? in_nhwc : (const void*)base[plan->layers[D.src].slot];
+                    a.x = L.fuse_src2 >= 0 ? nullptr : (D.src < 0 ? in_nhwc : (const void*)base[plan->layers[D.src].slot]);
                     a.w = D.w_f32; a.bias = D.bias; a.slope = D.slope; a.y = nullptr;
                     a.N = N; a.H = D.inH; a.W = D.inW; a.C = D.C; a.Ho = D.H; a.Wo = D.W; a.pad = D.pad; a.act = D.act;
                     a.zeros = plan->zeros;
-                    rc = launch_dwp(D.k, D.stride, a, L.w_packed, EpiArgs{L.bias, L.slope, res, y, L.cout, L.act}, st);
+                    DwpExpand ex{};
+                    if (L.fuse_src2 >= 0) {
+                        const Layer& E = plan->layers[L.fuse_src2];
+                        ex.xin = reinterpret_cast<const bf16*>(E.src < 0 ? in_nhwc : (const void*)base[plan->layers[E.src].slot]);
+                        ex.we = E.w_packed; ex.bias = E.bias; ex.slope = E.slope; ex.act = E.act; ex.Cin = E.K;
+                    }
+                    rc = launch_dwp(D.k, D.stride, a, L.w_packed, EpiArgs{L.bias, L.slope, res, y, L.cout, L.act},
+                                    L.fuse_src2 >= 0 ? &ex : nullptr, st);
                     break;
                 }
                 if (L.via_conv) {

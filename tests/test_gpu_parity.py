@@ -131,6 +131,29 @@ def test_fused_depthwise_pointwise_equals_unfused(name, golden_x):
     assert "dwp_kernel" in names
 
 
+@pytest.mark.parametrize("name", ["mobilenetv3_large", "mobilenetv3_small", "mobilenetv2"])
+def test_fused_expand_depthwise_pointwise_equals_unfused(name, golden_x, monkeypatch):
+    """FR_FUSE3=1 (opt-in) also computes the expand 1x1 conv of an inverted-residual block inside dwp_kernel:
+    same MFMA k order and the same bf16 rounding points as the three separate kernels, so bit-identical."""
+    x = golden_x.to(DEV)
+    m = product(name)
+    with torch.no_grad():
+        b = m(x, precision="bf16", fuse=False)
+    monkeypatch.setenv("FR_FUSE3", "1")
+    m.invalidate()                                   # plans read FR_FUSE3 when they are created
+    try:
+        with torch.no_grad():
+            a = m(x, precision="bf16", fuse=True)
+            big = m(x.repeat(5, 1, 1, 1), precision="bf16", fuse=True)
+        names = [r[1] for r in m.plan(DEV, "bf16", True).profile(x)]
+    finally:
+        m.invalidate()
+    assert torch.equal(a, b)
+    assert torch.equal(big.view(5, len(x), -1), b.unsqueeze(0).expand(5, -1, -1))
+    fused = [i for i in range(2, len(names)) if names[i] == "dwp_kernel" and names[i - 1].startswith("(fused") and names[i - 2].startswith("(fused")]
+    assert fused, names
+
+
 def test_batch_sizes_and_determinism(golden_x):
     m = product("mobilenetv3_small")
     x = golden_x.to(DEV)
