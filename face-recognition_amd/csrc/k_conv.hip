@@ -17,7 +17,7 @@
 #define CV_ROW 80     // bytes per LDS row: 32 bf16 + 16 B pad
 
 template <typename TIn, typename TOut, int TI, int TJ, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     constexpr bool SPLIT = std::is_same<TIn, float>::value;
     constexpr int NS = SPLIT ? 2 : 1;
     constexpr int BN = 32 * TI * WM, BM = 32 * TJ * WN;
@@ -184,7 +184,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 template <typename TOut, int TI, int TJ, int WM, int WN, int BK>
-__global__ __launch_bounds__(256) void conv_glds_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
     constexpr int BN = 32 * TI * WM, BM = 32 * TJ * WN;
     static_assert(WM * WN == 4 && BM == 128, "4 waves, 128 pixels per block");
     static_assert(BK == 32 || BK == 64, "K slice of 32 or 64 channels");

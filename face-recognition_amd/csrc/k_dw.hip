@@ -335,7 +335,6 @@ struct DwpArgs {
 template <int KSE, int NTE, int ACT, bool MASK>
 FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, const float* bel, const float* sel,
                        int gy0, int gx0, int wave, int lane) {
-    typedef short __attribute__((ext_vector_type(2))) s16x2;
     const DwArgs& a = x.dw;
     const int IW = g.IW, npin = g.IH * IW;
     const int pe = lane & 31, he = lane >> 5;
@@ -385,13 +384,8 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
                 for (int i = 0; i < 4; ++i) { v.v[i] = acc[8 * gg + i] + bb[t][2 * gg][i]; v.v[4 + i] = acc[8 * gg + 4 + i] + bb[t][2 * gg + 1][i]; }
                 u32x4 r;
                 if constexpr (ACT == FR_ACT_RELU) {
-                    // max(.,0) on the packed bf16 pairs: a negative float is a negative int16, so one
-                    // v_pk_max_i16 does two channels; same bits as rounding max(v, 0)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const s16x2 h = __builtin_bit_cast(s16x2, pack2bf(v.v[2 * i], v.v[2 * i + 1]));
-                        r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(h, s16x2{0, 0}));
-                    }
+                    for (int i = 0; i < 4; ++i) r[i] = pack2bf(relu1(v.v[2 * i]), relu1(v.v[2 * i + 1]));
                 } else {
                     if constexpr (ACT == FR_ACT_HSWISH) {
 #pragma unroll

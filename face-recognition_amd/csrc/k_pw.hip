@@ -69,7 +69,7 @@ struct XFrag<float> {
 };
 
 template <typename TIn, typename TOut, int NTB>
-__global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a, PwGrid pg) {
+__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwArgs a, PwGrid pg) {
     constexpr bool SPLIT = std::is_same<TIn, float>::value;
     constexpr int NS = SPLIT ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -333,7 +333,7 @@ static int launch_pw_proj(const PwArgs& a, hipStream_t st) {
 // block covers whole output rows (one column group), so that the 32-pixel tile leaves as ONE linear
 // run (a trailing 8- or 16-channel group of its own would again write 16/32-byte pieces).
 template <typename TOut, int NTB, int MT, int KSM = 8 / MT, int SG = (NTB < 2 ? NTB : 2)>
-__global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a, PwGrid pg) {
+__global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;

@@ -11,7 +11,7 @@
 #include "kernels.h"
 
 template <typename TOut, bool SPLIT>
-__global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
+__global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
     constexpr int NS = SPLIT ? 2 : 1;
     constexpr int TH = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
