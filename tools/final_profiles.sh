@@ -1,0 +1,12 @@
+# usage (on the GPU box): bash tools/final_profiles.sh  -- kernel-trace stats of the three workloads + default bench line
+set -e
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/final
+mkdir -p $O
+cd $R
+timeout -k 10 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_mnv3 -- python3 $R/bench.py --steps 10 --warmup 3 --no-search --no-cpu-baseline --no-layer-profile > $O/prof_mnv3.json 2>/dev/null
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_s64 -- python3 $R/bench.py --model sphere64 --batch 512 --steps 10 --warmup 3 --no-search --no-cpu-baseline --no-layer-profile > $O/prof_s64.json 2>/dev/null
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_search -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-layer-profile > $O/prof_search.json 2>/dev/null
+echo done
