@@ -96,7 +96,10 @@ int fr_plan_num_launches(const fr_plan* plan);
 /* Replaces: `model(tensor)` under torch.no_grad() (inference.py:121-122, evaluate.py:191-192).
  * x: fp32 NCHW [batch,in_c,in_h,in_w].  out: fp32; if the last layer is LINEAR it is
  * [batch,out_features], otherwise the last activation as NCHW fp32.  Raw, un-normalised, as the
- * reference backbones return (utils/layers.py:188-191). */
+ * reference backbones return (utils/layers.py:188-191).
+ * Asynchronous on `stream`.  A batch of 128 images or more is cut into two sub-batches, the second of
+ * which runs on an auxiliary stream owned by the plan (forked from and joined back to `stream` with
+ * events), so one plan serves one host thread at a time; results do not depend on the split. */
 int fr_embed(const fr_plan* plan, const float* x, int batch, float* out,
              void* workspace, size_t workspace_bytes, void* stream);
 /* Same, and additionally writes the output of layer `tap_layer` as fp32 NCHW to tap_out
