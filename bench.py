@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--model", default="mobilenetv3_large")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--input", default="f32", choices=["f32", "u8"],
+                    help="f32: normalised fp32 NCHW tensors, the reference's model(tensor) contract (default); "
+                         "u8: uint8 HWC faces through fr_embed_u8 (transform fused into the stem kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--gallery", type=int, default=0,
@@ -174,13 +177,18 @@ def main():
             rows = plan.profile(x)
             acc = [r[2] for r in rows] if acc is None else [p + r[2] for p, r in zip(acc, rows)]
         ms_layer = [v / reps for v in acc]
+    if a.input == "u8":
+        xin = ((x * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        step = model.forward_u8
+    else:
+        xin, step = x, model
     with torch.no_grad():
         for _ in range(a.warmup):
-            y = model(x)
+            y = step(xin)
         sync(dev, world)
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            y = model(x)
+            y = step(xin)
         sync(dev, world)
     dt = max_over_ranks(time.perf_counter() - t0, dev, world)
     ms = dt / a.steps * 1e3
@@ -191,7 +199,8 @@ def main():
     line = {"metric": "embeddings/sec", "value": round(value, 1), "unit": "embeddings/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": f"{a.model} batch-{a.batch} {a.precision} embedding extraction, 112x112 synthetic faces, "
+            "config": {"workload": f"{a.model} batch-{a.batch} {a.precision} embedding extraction, 112x112 synthetic faces"
+                                   f"{' (uint8 HWC input, transform in the stem kernel)' if a.input == 'u8' else ''}, "
                                    f"random-init weights ({cfg_name})",
                        "global_batch": a.batch * world, "parallelism": f"replicas x{world} (no collective)"}}
 

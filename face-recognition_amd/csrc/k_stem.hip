@@ -8,9 +8,16 @@
 // (zero padded), each wave builds the im2col "B" fragments of a 4x8-pixel sub-tile from LDS
 // (k = c*9 + ky*3 + kx, the natural order of weight.reshape(cout, 27)) and multiplies by the
 // register-resident weight fragments.  Output layout/epilogue are shared with the pointwise GEMM.
+//
+// U8 form (fr_embed_u8): the network input is the uint8 HWC image itself.  The block stages the raw
+// bytes of its patch rows (4-byte LDS-DMA of the word-aligned superset of each row span) and a
+// 256-entry table of ((b / 255) - 0.5) / 0.5 -- ToTensor + Normalize(0.5, 0.5) of inference.py:102-106,
+// computed on the host in the same fp32 operations -- and converts bytes to the fp32 patch in LDS
+// (0 outside the image: the conv pads the NORMALISED tensor).  From there on both forms are the same
+// code, so the results are bit-identical to feeding the transformed fp32 tensor.
 #include "kernels.h"
 
-template <typename TOut, bool SPLIT>
+template <typename TOut, bool SPLIT, bool U8>
 __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
     constexpr int NS = SPLIT ? 2 : 1;
     constexpr int TH = 8;
@@ -31,7 +38,48 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
     // issued before the single wait; pixels outside the image read the zero page.  A block owns an
     // 8-row strip of (up to) the whole image width: 100 k tiny blocks of 8x16 pixels were bound by
     // workgroup turnover, not by memory.
-    {
+    if constexpr (U8) {
+        unsigned char* raw = smem + a.raw_off;
+        const float* lut = reinterpret_cast<const float*>(smem + a.raw_off + a.lut_off);
+        const int RP = a.raw_pitch, WPR = RP >> 2;                   // bytes / words per staged row
+        const int gxs = gx0 < 0 ? 0 : gx0;
+        const int gxe = min(gx0 + IW, a.W);
+        const int span = (gxe - gxs) * 3;                            // bytes of one row inside the image
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.lut + threadIdx.x),
+                                         (__attribute__((address_space(3))) void*)(smem + a.raw_off + a.lut_off + wave * 256), 4, 0, 0);
+        const FastDiv d_wpr(WPR);
+        const int units = IH * WPR;
+        for (int i0 = wave * 64; i0 < units; i0 += 256) {
+            const int i = i0 + lane;
+            if (i < units) {
+                unsigned iy, j;
+                d_wpr.divmod(i, iy, j);
+                const int gy = gy0 + (int)iy;
+                const size_t b0 = (((size_t)n * a.H + (gy < 0 ? 0 : gy)) * a.W + gxs) * 3;
+                const int mis = (int)(b0 & 3);
+                const bool ok = gy >= 0 && gy < a.H && (int)j * 4 < mis + span;
+                const unsigned char* src = ok ? a.x8 + (b0 - mis) + j * 4 : reinterpret_cast<const unsigned char*>(a.zeros);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(raw + i0 * 4), 4, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int total = 3 * IH * IW;
+        const FastDiv d_hw(IH * IW), d_w(IW);
+        for (int i = threadIdx.x; i < total; i += 256) {
+            unsigned c, rem, iy, ix;
+            d_hw.divmod(i, c, rem);
+            d_w.divmod(rem, iy, ix);
+            const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
+            float v = 0.f;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const unsigned mis = (unsigned)((((size_t)n * a.H + gy) * a.W + gxs) * 3) & 3u;
+                v = lut[raw[iy * RP + mis + (gx - gxs) * 3 + c]];
+            }
+            patch[i] = v;
+        }
+    } else {
         const int total = 3 * IH * IW;
         const FastDiv d_hw(IH * IW), d_w(IW);
         for (int i0 = wave * 64; i0 < total; i0 += 256) {
@@ -131,8 +179,18 @@ int launch_stem(bool out_f32, const StemArgs& a, hipStream_t st) {
     if (!out_f32) lds += 4 * 32 * (64 + 16);
     const long blocks = (long)a.N * cdiv(a.Ho, 8) * cdiv(a.Wo, b.TW);
     if (blocks > 0x7FFFFFFFL) FR_FAIL(FR_ERR_ARG, "stem: grid too large");
-    if (out_f32) hipLaunchKernelGGL((stem_kernel<float, true>), dim3((unsigned)blocks), dim3(256), lds, st, b);
-    else hipLaunchKernelGGL((stem_kernel<bf16, false>), dim3((unsigned)blocks), dim3(256), lds, st, b);
+    if (a.x8) {
+        // rows are staged as the word-aligned superset of their bytes: the base must be word aligned and an
+        // image must be a whole number of words, so that the superset never leaves the caller's buffer
+        if (!a.lut || ((size_t)a.x8 & 3) || ((size_t)a.H * a.W * 3) % 4) FR_FAIL(FR_ERR_UNSUPPORTED, "stem (uint8 input): needs a 4-byte aligned buffer and H*W*3 % 4 == 0");
+        b.raw_off = (int)align_up(lds, 16);
+        b.raw_pitch = (3 * IW + 3 + 3) & ~3;
+        b.lut_off = (int)align_up((size_t)IH * b.raw_pitch, 16);
+        lds = (size_t)b.raw_off + b.lut_off + 1024;
+        if (out_f32) hipLaunchKernelGGL((stem_kernel<float, true, true>), dim3((unsigned)blocks), dim3(256), lds, st, b);
+        else hipLaunchKernelGGL((stem_kernel<bf16, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, b);
+    } else if (out_f32) hipLaunchKernelGGL((stem_kernel<float, true, false>), dim3((unsigned)blocks), dim3(256), lds, st, b);
+    else hipLaunchKernelGGL((stem_kernel<bf16, false, false>), dim3((unsigned)blocks), dim3(256), lds, st, b);
     FR_LAUNCH_CHECK("stem_kernel");
     return FR_OK;
 }

@@ -59,6 +59,10 @@ struct StemArgs {
     const void* zeros;    // >= 16 B of device zeros (LDS-DMA source outside the image)
     int stage_off;        // set by the launcher: LDS offset of the output staging tiles
     int TW;               // set by the launcher: output columns per block (8-row strips)
+    // uint8 HWC input (fr_embed_u8): x8 != nullptr replaces x; lut = 256 floats ((b/255)-0.5)/0.5
+    const unsigned char* x8;
+    const float* lut;
+    int raw_off, raw_pitch, lut_off;   // set by the launcher
 };
 int launch_stem(bool out_f32, const StemArgs& a, hipStream_t st);
 

@@ -55,6 +55,7 @@ struct fr_plan {
     int device = 0;
     int launches = 0;
     void* zeros = nullptr;                // 256 B of zeros (padding source of the LDS-DMA conv path)
+    float* u8_lut = nullptr;              // ((b / 255) - 0.5) / 0.5 for b = 0..255 (fr_embed_u8)
     // fr_embed runs the two halves of a large batch on the caller's stream and on this auxiliary
     // stream (fork/join by events): each half's kernel tails and launch gaps are filled by the other half
     static constexpr int MAX_AUX = 3;
@@ -330,6 +331,15 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         uint32_t* zp = nullptr;
         int rc = upload(pl.get(), z, &zp); if (rc) return rc;
         pl->zeros = zp;
+        // ToTensor (b / 255) then Normalize(0.5, 0.5) ((t - 0.5) / 0.5) of inference.py:102-106, in the same
+        // fp32 operations as torchvision performs them, tabulated once
+        std::vector<float> lut(256);
+        for (int b = 0; b < 256; ++b) {
+            volatile float t = (float)b / 255.0f;
+            volatile float u = t - 0.5f;
+            lut[b] = u / 0.5f;
+        }
+        rc = upload(pl.get(), lut, &pl->u8_lut); if (rc) return rc;
     }
     for (int i = 0; i < fr_plan::MAX_AUX; ++i) {
         FR_HIP_CHECK(hipStreamCreateWithFlags(&pl->aux[i], hipStreamNonBlocking));
@@ -462,10 +472,14 @@ extern "C" int fr_plan_layer_dims(const fr_plan* plan, int layer, int* c, int* h
 
 extern "C" int fr_plan_num_launches(const fr_plan* plan) { return plan ? plan->launches : FR_ERR_ARG; }
 
-static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out,
+// x_u8: `xv` is uint8 NHWC [batch,in_h,in_w,3] (fr_embed_u8) instead of fp32 NCHW.
+static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch, float* out,
                       void* workspace, size_t workspace_bytes, void* stream,
                       int tap_layer, float* tap_out, hipEvent_t* events) {
-    if (!plan || !x || !out || batch <= 0) FR_FAIL(FR_ERR_ARG, "fr_embed: bad arguments");
+    if (!plan || !xv || !out || batch <= 0) FR_FAIL(FR_ERR_ARG, "fr_embed: bad arguments");
+    if (x_u8 && (plan->in_c != 3 || plan->input_slot >= 0 || plan->layers.empty() || plan->layers[0].kind != K_STEM))
+        FR_FAIL(FR_ERR_UNSUPPORTED, "fr_embed_u8: the plan's first layer is not a 3-channel 3x3 stem");
+    const float* x = x_u8 ? nullptr : static_cast<const float*>(xv);
     (void)events;
     const size_t need = plan_ws_exact(plan, batch);
     if (!workspace || workspace_bytes < need) FR_FAIL(FR_ERR_WORKSPACE, "fr_embed: workspace too small");
@@ -513,6 +527,7 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
                 a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act};
                 a.N = N; a.H = L.inH; a.W = L.inW; a.Ho = L.H; a.Wo = L.W; a.stride = L.stride; a.NT = L.NT;
                 a.zeros = plan->zeros;
+                if (x_u8) { a.x8 = static_cast<const unsigned char*>(xv); a.lut = plan->u8_lut; }
                 rc = launch_stem(L.out_f32, a, st);
                 break;
             }
@@ -623,7 +638,7 @@ static int embed_impl(const fr_plan* plan, const float* x, int batch, float* out
 extern "C" int fr_embed_tap(const fr_plan* plan, const float* x, int batch, float* out,
                             void* workspace, size_t workspace_bytes, void* stream,
                             int tap_layer, float* tap_out) {
-    return embed_impl(plan, x, batch, out, workspace, workspace_bytes, stream, tap_layer, tap_out, nullptr);
+    return embed_impl(plan, x, false, batch, out, workspace, workspace_bytes, stream, tap_layer, tap_out, nullptr);
 }
 
 extern "C" int fr_embed_profile(const fr_plan* plan, const float* x, int batch, float* out,
@@ -632,7 +647,7 @@ extern "C" int fr_embed_profile(const fr_plan* plan, const float* x, int batch, 
     const int nl = (int)plan->layers.size();
     std::vector<hipEvent_t> ev(nl + 1);
     for (auto& e : ev) FR_HIP_CHECK(hipEventCreate(&e));
-    int rc = embed_impl(plan, x, batch, out, workspace, workspace_bytes, stream, -1, nullptr, ev.data());
+    int rc = embed_impl(plan, x, false, batch, out, workspace, workspace_bytes, stream, -1, nullptr, ev.data());
     if (rc == FR_OK) {
         hipError_t he = hipEventSynchronize(ev[nl]);
         if (he != hipSuccess) { fr_set_error(std::string("hipEventSynchronize: ") + hipGetErrorString(he)); rc = FR_ERR_HIP; }
@@ -664,8 +679,9 @@ extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char**
     return FR_OK;
 }
 
-extern "C" int fr_embed(const fr_plan* plan, const float* x, int batch, float* out,
-                        void* workspace, size_t workspace_bytes, void* stream) {
+static int embed_split(const fr_plan* plan, const void* xv, bool x_u8, int batch, float* out,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    const unsigned char* x = static_cast<const unsigned char*>(xv);
     // Large batches are cut into `parts` independent sub-batches, the first on the caller's stream and
     // the others on the plan's auxiliary streams (fork/join by events, still asynchronous): kernel
     // tails, launch gaps and the last partially filled wave of workgroups of one part are filled by
@@ -683,14 +699,14 @@ extern "C" int fr_embed(const fr_plan* plan, const float* x, int batch, float* o
         if (workspace_bytes >= off[parts]) {
             hipStream_t st = (hipStream_t)stream;
             const Layer& last = plan->layers.back();
-            const size_t in_el = (size_t)plan->in_c * plan->in_h * plan->in_w;
+            const size_t in_el = (size_t)plan->in_c * plan->in_h * plan->in_w * (x_u8 ? 1 : sizeof(float));   // bytes per image
             const size_t out_el = (size_t)last.C * last.H * last.W;
             FR_HIP_CHECK(hipEventRecord(plan->ev_fork, st));
             int rc = FR_OK;
             for (int i = 0; i < parts && !rc; ++i) {
                 hipStream_t si = i == 0 ? st : plan->aux[i - 1];
                 if (i > 0) FR_HIP_CHECK(hipStreamWaitEvent(si, plan->ev_fork, 0));
-                rc = embed_impl(plan, x + (size_t)n0[i] * in_el, n0[i + 1] - n0[i], out + (size_t)n0[i] * out_el,
+                rc = embed_impl(plan, x + (size_t)n0[i] * in_el, x_u8, n0[i + 1] - n0[i], out + (size_t)n0[i] * out_el,
                                 reinterpret_cast<unsigned char*>(workspace) + off[i], off[i + 1] - off[i], si, -1, nullptr, nullptr);
                 if (i > 0) {
                     FR_HIP_CHECK(hipEventRecord(plan->ev_join[i - 1], si));
@@ -700,5 +716,15 @@ extern "C" int fr_embed(const fr_plan* plan, const float* x, int batch, float* o
             return rc;
         }
     }
-    return fr_embed_tap(plan, x, batch, out, workspace, workspace_bytes, stream, -1, nullptr);
+    return embed_impl(plan, xv, x_u8, batch, out, workspace, workspace_bytes, stream, -1, nullptr, nullptr);
+}
+
+extern "C" int fr_embed(const fr_plan* plan, const float* x, int batch, float* out,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    return embed_split(plan, x, false, batch, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int fr_embed_u8(const fr_plan* plan, const unsigned char* x_nhwc, int batch, float* out,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    return embed_split(plan, x_nhwc, true, batch, out, workspace, workspace_bytes, stream);
 }

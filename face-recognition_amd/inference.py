@@ -90,9 +90,10 @@ def embed_images(model, device, images: Sequence[np.ndarray], batch_size: int = 
     outs: List[torch.Tensor] = []
     with torch.no_grad():
         for i in range(0, len(images), batch_size):
-            a = np.stack(images[i:i + batch_size])
-            t = torch.from_numpy(a).to(device).permute(0, 3, 1, 2).to(torch.float32).div(255)
-            outs.append(model((t - 0.5) / 0.5))
+            a = np.ascontiguousarray(np.stack(images[i:i + batch_size]))
+            # the uint8 faces go to the GPU as they are (37.6 KB each); /255 and Normalize(0.5, 0.5) happen in
+            # the stem kernel's load (fr_embed_u8), bit-identical to model(transform(img))
+            outs.append(model.forward_u8(torch.from_numpy(a).to(device)))
     return torch.cat(outs) if outs else torch.empty(0, 512, device=device)
 
 

@@ -199,6 +199,18 @@ class HipBackbone(nn.Module):
             raise ValueError(f"expected input [N,3,112,112], got {tuple(x.shape)}")
         return self.plan(x.device, precision, fuse).run(x)
 
+    def forward_u8(self, x: torch.Tensor, precision: Optional[str] = None, fuse: Optional[bool] = None) -> torch.Tensor:
+        """uint8 [N,112,112,3] RGB faces on the GPU -> embeddings: ``model(transform(img))`` of
+        inference.py:98-106,:120-122 with ToTensor + Normalize applied inside the stem kernel's load
+        (fr_embed_u8).  Bit-identical to ``forward`` on the transformed tensor."""
+        if self.training:
+            raise RuntimeError("HipBackbone runs inference only: call .eval() first (reference: inference.py:92)")
+        if not x.is_cuda:
+            raise RuntimeError("HipBackbone.forward_u8 needs a GPU tensor: the hot path has no CPU fallback")
+        if x.dtype != torch.uint8 or x.dim() != 4 or tuple(x.shape[1:]) != (112, 112, 3):
+            raise ValueError(f"expected uint8 input [N,112,112,3], got {x.dtype} {tuple(x.shape)}")
+        return self.plan(x.device, precision, fuse).run_u8(x)
+
     def forward_tap(self, x: torch.Tensor, layer: int, precision: Optional[str] = None):
         """(embedding, output of plan layer ``layer`` as fp32 NCHW) -- parity tests."""
         return self.plan(x.device, precision, fuse=False).run(x, tap=layer)
@@ -261,6 +273,10 @@ class _Plan:
             _lib.check(self.lib.fr_plan_layer_kernel(self.handle, i, C.byref(nm)), "fr_plan_layer_kernel")
             rows.append((self.names[i], nm.value.decode(), float(ms[i]), self.srcs[i]))
         return rows
+
+    def run_u8(self, x: torch.Tensor) -> torch.Tensor:
+        c, h, w = self.dims[-1]
+        return torch.ops.fr_hip.embed_u8(x, int(self.handle.value), c, h, w)        # ops.py -> fr_embed_u8
 
     def run(self, x: torch.Tensor, tap: int = -1):
         x = x.to(torch.float32).contiguous()

@@ -9,6 +9,7 @@ exactly one C-ABI call on the current torch stream (include/fr_hip.h names the r
 call replaces).
 
     torch.ops.fr_hip.embed(x, plan, out_c, out_h, out_w)      model(tensor)        inference.py:121-122
+    torch.ops.fr_hip.embed_u8(x, plan, out_c, out_h, out_w)   transform + model    inference.py:98-106,:120-122
     torch.ops.fr_hip.cosine_pairs(a, b, eps, threshold)       similarity formulas  utils/face_utils.py:84-87, evaluate.py:554,:204-206
     torch.ops.fr_hip.l2norm_bf16(x)                           gallery/query rows   (no counterpart)
     torch.ops.fr_hip.topk_search(q, g, k, idx_offset)         1:N search           (no counterpart)
@@ -26,6 +27,7 @@ from . import _lib
 _NS = "fr_hip"
 _defs = torch.library.Library(_NS, "DEF")
 _defs.define("embed(Tensor x, int plan, int out_c, int out_h, int out_w) -> Tensor")
+_defs.define("embed_u8(Tensor x, int plan, int out_c, int out_h, int out_w) -> Tensor")
 _defs.define("cosine_pairs(Tensor a, Tensor b, float eps, float threshold) -> (Tensor, Tensor)")
 _defs.define("l2norm_bf16(Tensor x) -> Tensor")
 _defs.define("topk_search(Tensor q, Tensor g, int k, int idx_offset) -> (Tensor, Tensor)")
@@ -60,9 +62,7 @@ def _out_shape(n, c, h, w):
     return (n, c) if (h, w) == (1, 1) else (n, c, h, w)
 
 
-def _embed(x, plan, out_c, out_h, out_w):
-    if x.dtype != torch.float32 or x.dim() != 4:
-        raise RuntimeError("fr_hip::embed: expected a float32 [N,C,H,W] tensor")
+def _embed_any(x, plan, out_c, out_h, out_w, u8):
     x = x.contiguous()
     n = x.shape[0]
     out = torch.empty(_out_shape(n, out_c, out_h, out_w), dtype=torch.float32, device=x.device)
@@ -72,10 +72,22 @@ def _embed(x, plan, out_c, out_h, out_w):
     need = C.c_size_t()
     _lib.check(lib.fr_plan_workspace_bytes(C.c_void_p(plan), n, C.byref(need)), "fr_plan_workspace_bytes")
     ws = _workspace(plan, x.device, need.value)
+    fn, name = (lib.fr_embed_u8, "fr_embed_u8") if u8 else (lib.fr_embed, "fr_embed")
     with torch.cuda.device(x.device):
-        _lib.check(lib.fr_embed(C.c_void_p(plan), x.data_ptr(), n, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                _stream(x.device)), "fr_embed")
+        _lib.check(fn(C.c_void_p(plan), x.data_ptr(), n, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x.device)), name)
     return out
+
+
+def _embed(x, plan, out_c, out_h, out_w):
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise RuntimeError("fr_hip::embed: expected a float32 [N,C,H,W] tensor")
+    return _embed_any(x, plan, out_c, out_h, out_w, False)
+
+
+def _embed_u8(x, plan, out_c, out_h, out_w):
+    if x.dtype != torch.uint8 or x.dim() != 4 or x.shape[3] != 3:
+        raise RuntimeError("fr_hip::embed_u8: expected a uint8 [N,H,W,3] tensor")
+    return _embed_any(x, plan, out_c, out_h, out_w, True)
 
 
 def _cosine_pairs(a, b, eps, threshold):
@@ -143,6 +155,7 @@ def _topk_merge(scores, idx, k):
 
 
 _impl.impl("embed", _embed)
+_impl.impl("embed_u8", _embed_u8)
 _impl.impl("cosine_pairs", _cosine_pairs)
 _impl.impl("l2norm_bf16", _l2norm_bf16)
 _impl.impl("topk_search", _topk_search)
@@ -150,6 +163,7 @@ _impl.impl("topk_merge", _topk_merge)
 
 # shape functions (tracing / torch.export)
 _meta.impl("embed", lambda x, plan, c, h, w: x.new_empty(_out_shape(x.shape[0], c, h, w), dtype=torch.float32))
+_meta.impl("embed_u8", lambda x, plan, c, h, w: x.new_empty(_out_shape(x.shape[0], c, h, w), dtype=torch.float32))
 _meta.impl("cosine_pairs", lambda a, b, eps, thr: (a.new_empty(a.shape[0], dtype=torch.float32),
                                                    a.new_empty(a.shape[0], dtype=torch.bool)))
 _meta.impl("l2norm_bf16", lambda x: x.new_empty(x.shape, dtype=torch.bfloat16))

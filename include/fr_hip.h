@@ -102,6 +102,15 @@ int fr_plan_num_launches(const fr_plan* plan);
  * events), so one plan serves one host thread at a time; results do not depend on the split. */
 int fr_embed(const fr_plan* plan, const float* x, int batch, float* out,
              void* workspace, size_t workspace_bytes, void* stream);
+/* Replaces: `get_transform()(img)` + `model(tensor)` (inference.py:98-106 and :120-122) for images that
+ * are already 112x112 RGB: x_nhwc is uint8 [batch,in_h,in_w,3] (what PIL / the aligner hands over, 37.6 KB
+ * per face instead of 150 KB of fp32).  ToTensor (/255) and Normalize(0.5, 0.5) are applied inside the
+ * stem kernel's load with the same fp32 arithmetic, so the result is bit-identical to fr_embed on the
+ * transformed tensor.  Resize is NOT performed (the reference's Resize((112,112)) is the identity for such
+ * input).  Needs a plan whose first layer is the 3x3 stem (all 7 backbones), a 4-byte aligned x_nhwc and
+ * in_h*in_w*3 divisible by 4; FR_ERR_UNSUPPORTED otherwise.  SURVEY.md 8(f) rank 2. */
+int fr_embed_u8(const fr_plan* plan, const unsigned char* x_nhwc, int batch, float* out,
+                void* workspace, size_t workspace_bytes, void* stream);
 /* Same, and additionally writes the output of layer `tap_layer` as fp32 NCHW to tap_out
  * (parity tests of intermediate blocks; no reference counterpart beyond forward hooks). */
 int fr_embed_tap(const fr_plan* plan, const float* x, int batch, float* out,

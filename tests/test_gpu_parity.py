@@ -154,6 +154,32 @@ def test_fused_expand_depthwise_pointwise_equals_unfused(name, golden_x, monkeyp
     assert fused, names
 
 
+@pytest.mark.parametrize("name,precision", [("mobilenetv3_small", "bf16"), ("mobilenetv3_small", "f32"), ("mobilenetv1", "bf16"),
+                                            ("sphere20", "bf16"), ("sphere20", "f32")])
+def test_uint8_input_equals_transformed_input(name, precision, golden_inputs, golden_x):
+    """fr_embed_u8 (uint8 HWC faces, ToTensor + Normalize(0.5, 0.5) inside the stem kernel's load; SURVEY 8(f)
+    rank 2) against fr_embed on the oracle's transform of the same images (inference.py:98-106, pinned by
+    test_host.py::test_transform_matches_oracle): bit for bit, for the stride-1 (MobileNet) and the stride-2
+    (SphereFace) stem, in both precisions, and across the two-stream split with a ragged batch."""
+    import numpy as np
+    m = product(name)
+    u8 = torch.from_numpy(np.ascontiguousarray(golden_inputs)).to(DEV)
+    assert u8.dtype == torch.uint8 and tuple(u8.shape[1:]) == (112, 112, 3)
+    rng = np.random.default_rng(5)
+    noise = torch.from_numpy(rng.integers(0, 256, size=(3, 112, 112, 3), dtype=np.uint8)).to(DEV)   # every byte value, hard edges
+    u8 = torch.cat([u8, noise])
+    x = torch.stack([osc.to_model_input(im) for im in u8.cpu().numpy()]).to(DEV)
+    with torch.no_grad():
+        a = m.forward_u8(u8, precision=precision)
+        b = m(x, precision=precision)
+        big = m.forward_u8(u8.repeat(19, 1, 1, 1)[:131], precision=precision)       # 131 images: split 65 + 66
+    assert torch.equal(a, b)
+    assert torch.equal(big, b.repeat(19, 1)[:131])
+    with pytest.raises(ValueError):
+        m.forward_u8(u8[:, :, :111], precision=precision)
+    assert m.forward_u8(u8[:0], precision=precision).shape == (0, 512)
+
+
 def test_batch_sizes_and_determinism(golden_x):
     m = product("mobilenetv3_small")
     x = golden_x.to(DEV)
