@@ -337,3 +337,34 @@ def test_embedding_to_gallery_roundtrip(golden_x):
     y, nrm = fr.search.l2norm(e)
     assert torch.allclose(y.norm(dim=1), torch.ones(8, device=DEV), atol=1e-5)
     assert torch.allclose(nrm, e.norm(dim=1), rtol=1e-5)
+
+
+def test_gallery_files_json_import_search_and_ids(tmp_path, golden_x):
+    """SURVEY.md 8(f) rank 3 end to end: reference-format JSON gallery (inference.py:153-160) -> import_json
+    (fr_l2norm_bf16 on the GPU) -> shard files -> per-rank load -> search -> ids.  The stored rows equal the
+    oracle's normalisation to bf16 rounding, and every enrolled face finds itself first."""
+    import json
+    from face_recognition_amd import gallery as G
+    m = product("mobilenetv3_small")
+    with torch.no_grad():
+        emb = m(golden_x.to(DEV).repeat(40, 1, 1, 1) + 0.05 * torch.randn(len(golden_x) * 40, 3, 112, 112, device=DEV), precision="f32")
+    names = [f"face_{i:03d}.jpg" for i in range(len(emb))]
+    j = str(tmp_path / "embeddings.json")
+    with open(j, "w") as f:
+        json.dump({n: e for n, e in zip(names, emb.cpu().tolist())}, f, indent=2)
+    g = G.import_json(j, str(tmp_path / "g"), DEV, shard_rows=100, chunk=64)
+    assert len(g) == len(emb) and g.ids == names
+    rows = g.load_rows(DEV)
+    e64 = emb.cpu().numpy().astype("float64")
+    ref = torch.from_numpy(e64 / np.linalg.norm(e64, axis=1, keepdims=True)).to(torch.float32)
+    assert torch.equal(rows, fr.search.normalize_rows_bf16(emb))
+    assert (rows.cpu().to(torch.float32) - ref).abs().max() <= 2.0 ** -8            # half a bf16 ulp below 1.0, with margin
+    matcher = g.matcher(DEV, k=3)
+    s, idx = matcher.search(rows)
+    assert [r[0] for r in g.lookup(idx)] == names
+    two = [g.matcher(DEV, rank=r, world=2, k=3).local.search(rows) for r in range(2)]
+    ms, mi = fr.search.merge_topk(torch.stack([t[0] for t in two]), torch.stack([t[1] for t in two]), 3)
+    assert torch.equal(mi, idx) and torch.equal(ms, s)
+    built = G.build_from_images(m, DEV, ["a", "b"], [(golden_x[i].permute(1, 2, 0) * 127.5 + 127.5).round().to(torch.uint8).numpy() for i in range(2)],
+                                str(tmp_path / "b"))
+    assert built.rows == 2 and built.ids == ["a", "b"]

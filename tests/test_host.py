@@ -148,3 +148,56 @@ def test_custom_ops_registered_and_refuse_cpu():
         torch.ops.fr_hip.topk_search(torch.zeros(2, 512, dtype=torch.bfloat16), torch.zeros(4, 512, dtype=torch.bfloat16), 5, 0)
     y = torch.ops.fr_hip.embed(torch.zeros(3, 3, 112, 112, device="meta"), 0, 512, 1, 1)
     assert tuple(y.shape) == (3, 512) and y.dtype == torch.float32
+
+
+def test_gallery_format_roundtrip_and_validation(tmp_path):
+    """On-disk gallery: shard files + id table, ranges across shard boundaries,
+    per-rank loading = the matcher's contiguous sharding, JSON export in the reference's format
+    (inference.py:153-160), and refusal of damaged directories."""
+    import json
+    from face_recognition_amd import gallery as G
+    torch.manual_seed(3)
+    rows = torch.nn.functional.normalize(torch.randn(1000, 512), dim=1).to(torch.bfloat16)
+    ids = [f"pessoa_{i}_é.jpg" if i % 7 == 0 else f"img{i:04d}.png" for i in range(1000)]
+    d = str(tmp_path / "g")
+    with G.GalleryWriter(d, 512, shard_rows=384) as w:
+        w.add_normalized(ids[:100], rows[:100])
+        w.add_normalized(ids[100:], rows[100:])           # crosses two shard boundaries in one call
+        with pytest.raises(RuntimeError):
+            w.add(ids[:1], torch.zeros(1, 512))            # raw embeddings are normalised on the GPU only
+        with pytest.raises(ValueError):
+            w.add_normalized(ids[:2], rows[:1])
+    g = G.open_gallery(d)
+    assert len(g) == 1000 and g.dim == 512 and g.ids == ids
+    assert sorted(f for f in os.listdir(d) if f.endswith(".bf16")) == ["rows-00000.bf16", "rows-00001.bf16", "rows-00002.bf16"]
+    assert os.path.getsize(os.path.join(d, "rows-00002.bf16")) == (1000 - 768) * 1024
+    assert torch.equal(g.load_rows("cpu"), rows)
+    assert torch.equal(g.load_rows("cpu", 380, 771), rows[380:771])
+    assert g.load_rows("cpu", 5, 5).shape == (0, 512)
+    with pytest.raises(IndexError):
+        g.load_rows("cpu", 10, 1001)
+    parts = [g.load_for_rank("cpu", r, 3) for r in range(3)]
+    assert [p[1] for p in parts] == [fr.search.shard_range(1000, r, 3)[0] for r in range(3)]
+    assert torch.equal(torch.cat([p[0] for p in parts]), rows)
+    assert g.lookup(torch.tensor([[0, 999, -1]])) == [[ids[0], ids[999], None]]
+    # the reference's JSON format
+    j = str(tmp_path / "out" / "embeddings.json")
+    G.export_json(g, j, chunk=300)
+    back = json.load(open(j))
+    assert list(back.keys()) == ids and back[ids[7]] == rows[7].to(torch.float32).tolist()
+    # an unfinished or damaged gallery does not open
+    with pytest.raises(FileExistsError):
+        G.GalleryWriter(d)
+    half = str(tmp_path / "half")
+    try:
+        with G.GalleryWriter(half, 512) as w:
+            w.add_normalized(ids[:3], rows[:3])
+            raise KeyboardInterrupt
+    except KeyboardInterrupt:
+        pass
+    with pytest.raises(FileNotFoundError):
+        G.open_gallery(half)
+    with open(os.path.join(d, "rows-00001.bf16"), "ab") as f:
+        f.write(b"\0\0")
+    with pytest.raises(ValueError):
+        G.open_gallery(d)
