@@ -30,7 +30,35 @@ struct DwGeom {          // derived launch geometry (host computed)
     int IH, IW, nstrips, nitems, nunits;
     int PP;              // LDS pitch of one tile pixel in 8-channel vectors (CBV, or CBV+1 when the tile is computed in the kernel)
     int n0;              // first image of this launch slice (blockIdx.z is relative to it)
+    // XCD-aware block order (dw_block): images in groups of 8, one image per XCD
+    Div32 d_per8, d_per, d_gx;
+    int per_img, full;   // blocks per image; blocks covered by whole groups of 8 images (0: identity order)
 };
+
+// Which (image, tile) a block works on.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order
+// and every XCD has its own L2: with the natural order the tiles of one image -- whose halos overlap --
+// land on 8 different L2s and each fetches the overlap from the fabric again (PMC: up to 3x the input
+// bytes on the 5x5 layers).  Here dispatch slot L goes to image 8*(L / (8*per_img)) + L % 8 and tile
+// (L / 8) % per_img, so one XCD walks through one image's tiles back to back.
+FR_DEV void dw_block(const DwGeom& g, int gx, int gy, int& bx, int& by, int& n) {
+    bx = blockIdx.x; by = blockIdx.y; n = blockIdx.z;
+    const unsigned L = blockIdx.x + (unsigned)gx * (blockIdx.y + (unsigned)gy * blockIdx.z);
+    if (L < (unsigned)g.full) {
+        const unsigned grp = div32(L, g.d_per8), r = L - grp * 8u * g.per_img;
+        const unsigned w = r >> 3;
+        n = (int)(grp * 8u + (r & 7u));
+        by = (int)div32(w, g.d_gx);
+        bx = (int)(w - (unsigned)by * gx);
+    }
+    n += g.n0;
+}
+
+static void dw_block_geom(DwGeom& g, int gx, int gy, int nslice) {
+    g.per_img = gx * gy;
+    const unsigned long long full = (unsigned long long)(nslice / 8) * 8ull * g.per_img;
+    g.full = (full * 8ull * g.per_img < (1ull << 32) && full < (1ull << 31)) ? (int)full : 0;
+    g.d_per8 = make_div32(8u * g.per_img); g.d_per = make_div32(g.per_img); g.d_gx = make_div32(gx);
+}
 
 template <int S> __host__ __device__ constexpr int dw_sw() { return S == 2 ? 2 : 4; }
 
@@ -147,8 +175,9 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SW = dw_sw<S>();                  // outputs per work item (see dw_pick_tile)
     const int CBV = a.CBV, CV = a.C >> 3;
-    const int cc = blockIdx.x % a.cchunks, tx = blockIdx.x / a.cchunks, ty = blockIdx.y;
-    const int n = g.n0 + blockIdx.z;
+    int bx, ty, n;
+    dw_block(g, a.tiles_x * a.cchunks, a.tiles_y, bx, ty, n);
+    const int cc = bx % a.cchunks, tx = bx / a.cchunks;
     const int cv0 = cc * CBV, ncv = min(CBV, CV - cv0);
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int IW = g.IW;
@@ -252,6 +281,7 @@ static int launch_dw_t(int k, int s, const DwArgs& a, DwGeom g, size_t lds, hipS
     for (int n0 = 0; n0 < a.N; n0 += 65535) {          // blockIdx.z carries the image
         g.n0 = n0;
         dim3 grid((unsigned)(a.tiles_x * a.cchunks), (unsigned)a.tiles_y, (unsigned)std::min(65535, a.N - n0));
+        dw_block_geom(g, (int)grid.x, (int)grid.y, (int)grid.z);
 #define FR_DW_CASE(KK, SS) if (k == KK && s == SS) { hipLaunchKernelGGL((dw_kernel<T, KK, SS>), grid, dim3(256), lds, st, a, g); }
         FR_DW_CASE(3, 1) else FR_DW_CASE(3, 2) else FR_DW_CASE(5, 1) else FR_DW_CASE(5, 2)
         else FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: only k in {3,5}, stride in {1,2}");
@@ -414,8 +444,8 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     constexpr int SW = dw_sw<S>();
     const DwArgs& a = x.dw;
     const int CBV = a.CBV;
-    const int tx = blockIdx.x, ty = blockIdx.y;
-    const int n = g.n0 + blockIdx.z;
+    int tx, ty, n;
+    dw_block(g, a.tiles_x, a.tiles_y, tx, ty, n);
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int IW = g.IW;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -640,6 +670,7 @@ int launch_dwp(int k, int stride, DwArgs a, const bf16* wp, const EpiArgs& e, co
     for (int n0 = 0; n0 < a.N; n0 += 65535) {
         g.n0 = n0;
         dim3 grid((unsigned)a.tiles_x, (unsigned)a.tiles_y, (unsigned)std::min(65535, a.N - n0));
+        dw_block_geom(g, (int)grid.x, (int)grid.y, (int)grid.z);
 #define FR_DWP_CASE(KK, SS) if (!ex && k == KK && stride == SS) hipLaunchKernelGGL((dwp_kernel<KK, SS, 0, 0>), grid, dim3(256), pl.lds, st, x, g);
 #define FR_DWX_CASE(SS, KE, NE) if (ex && k == 3 && stride == SS && x.KSe == KE && x.NTe == NE) \
         hipLaunchKernelGGL((dwp_kernel<3, SS, KE, NE>), grid, dim3(256), pl.lds, st, x, g);
