@@ -200,8 +200,25 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int p = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const long m0 = (long)blockIdx.x * BM;
-    const int nt0 = blockIdx.y;
+    // XCD-aware block order: workgroups go to the 8 XCDs round-robin in dispatch order and each XCD has its own
+    // L2.  Dispatch slot L = (XCD k = L % 8, turn j = L / 8) works on pixel tile k * (tiles / 8) + j / ny and
+    // cout tile j % ny: one XCD owns a contiguous range of pixel tiles (vertical halos of neighbouring tiles
+    // meet in one L2) and runs the cout tiles of a pixel tile back to back (the pixels are fetched once, not
+    // once per cout tile).  The last tiles % 8 pixel tiles keep the natural order.
+    unsigned pt = blockIdx.x, nt = blockIdx.y;
+    {
+        const unsigned gx = gridDim.x, ny = gridDim.y, per = gx >> 3, full = per * 8u * ny;
+        const unsigned L = blockIdx.x + gx * blockIdx.y;
+        if (L < full) {
+            const unsigned k = L & 7u, j = L >> 3, q = j / ny;
+            pt = k * per + q; nt = j - q * ny;
+        } else {
+            const unsigned rest = gx - 8u * per, Lt = L - full, q = Lt / rest;
+            pt = 8u * per + (Lt - q * rest); nt = q;
+        }
+    }
+    const long m0 = (long)pt * BM;
+    const int nt0 = (int)nt;
     const int chunks = a.Cin / BK;
     const int KS = a.ksize * a.ksize * chunks;
 
