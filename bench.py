@@ -162,6 +162,12 @@ def main():
     model.precision = a.precision
     x = synthetic_batch(a.batch, dev)
     ms_layer = rows = plan = None
+    # fr_embed cuts a batch >= FR_SPLIT_MIN (128) into FR_SPLIT_PARTS (2) sub-batches on two streams: one kernel
+    # launch processes one layer of ONE sub-batch, and that is what the per-launch figures below refer to
+    split_min = int(os.environ.get("FR_SPLIT_MIN", "128"))
+    parts = min(int(os.environ.get("FR_SPLIT_PARTS", "2")), 4)
+    parts = parts if (split_min > 0 and parts > 1 and a.batch >= split_min) else 1
+    pb = a.batch // parts
     if rank == 0 and not a.no_layer_profile:
         # ---- per-layer HIP-event timing on the launch stream (5 profiled passes, averaged); runs before the
         # warm-up, outside the timed region
@@ -172,9 +178,9 @@ def main():
         reps = 5
         acc = None
         for _ in range(3):                       # untimed: clocks and caches warm before the averaged passes
-            plan.profile(x)
+            plan.profile(x[:pb])
         for _ in range(reps):
-            rows = plan.profile(x)
+            rows = plan.profile(x[:pb])
             acc = [r[2] for r in rows] if acc is None else [p + r[2] for p, r in zip(acc, rows)]
         ms_layer = [v / reps for v in acc]
     if a.input == "u8":
@@ -205,8 +211,8 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"replicas x{world} (no collective)"}}
 
     if rank == 0 and ms_layer is not None:
-        alg = layer_alg_bytes(plan, a.batch)
-        flp = layer_alg_flops(plan, a.batch)
+        alg = layer_alg_bytes(plan, pb)
+        flp = layer_alg_flops(plan, pb)
         fam = {}
         carry_b = carry_f = 0.0
         for (name, kern, _, _), t, b, fl in zip(rows, ms_layer, alg, flp):
@@ -221,13 +227,13 @@ def main():
         # arithmetic intensity of the dominant family against the machine balance decides the bound
         if f_dom / b_dom > MFMA_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9):
             ach = f_dom / (t_dom * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": n_dom,
+            line["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": n_dom * parts, "images_per_launch": pb,
                                 "avg_launch_ms": round(t_dom / n_dom, 4), "alg_flops_per_launch": int(f_dom / n_dom),
                                 "achieved": round(ach, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
                                 "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": None}
         else:
             ach = b_dom / (t_dom * 1e-3) / 1e9
-            line["roofline"] = {"bound": "hbm", "kernel": dom, "launches_per_step": n_dom,
+            line["roofline"] = {"bound": "hbm", "kernel": dom, "launches_per_step": n_dom * parts, "images_per_launch": pb,
                                 "avg_launch_ms": round(t_dom / n_dom, 4), "alg_bytes_per_launch": int(b_dom / n_dom),
                                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
@@ -235,17 +241,17 @@ def main():
         if os.path.exists(tf):          # HBM bytes per launch from a separate rocprofv3 --pmc run (tools/hbm_traffic.py)
             k = json.load(open(tf)).get("kernels", {}).get(dom)
             if k:
-                line["roofline"]["traffic"] = int(k["hbm_bytes_per_step"] / n_dom)
+                line["roofline"]["traffic"] = int(k["hbm_bytes_per_step"] / (n_dom * parts))
                 line["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
         if a.model in ALG_MB_PER_IMG:
             whole = ALG_MB_PER_IMG[a.model] * 1e6 * a.batch / (ms * 1e-3) / 1e9
             line["whole_path"] = {"bound": "hbm", "alg_MB_per_image": ALG_MB_PER_IMG[a.model], "achieved": round(whole, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBS, 4),
-                                  "launches_per_step": plan.lib.fr_plan_num_launches(plan.handle),
-                                  "sum_layer_ms": round(sum(ms_layer), 4)}
-        line["kernel_families"] = {k: {"ms": round(v[0], 4), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0,
+                                  "launches_per_step": plan.lib.fr_plan_num_launches(plan.handle) * parts,
+                                  "sum_launch_ms": round(sum(ms_layer) * parts, 4)}
+        line["kernel_families"] = {k: {"ms": round(v[0] * parts, 4), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0,
                                         "TFLOPs": round(v[3] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0,
-                                        "launches": v[2]} for k, v in fam.items()}
+                                        "launches": v[2] * parts} for k, v in fam.items()}
         if a.layers:
             for (name, kern, _, _), t, b in zip(rows, ms_layer, alg):
                 print(f"{name:36s} {kern:22s} {t:8.4f} ms {b / (t * 1e-3) / 1e9 if t > 0 else 0:9.1f} GB/s", file=sys.stderr)
