@@ -31,7 +31,7 @@ struct DwGeom {          // derived launch geometry (host computed)
     int PP;              // LDS pitch of one tile pixel in 8-channel vectors (CBV, or CBV+1 when the tile is computed in the kernel)
     int n0;              // first image of this launch slice (blockIdx.z is relative to it)
     // XCD-aware block order (dw_block): images in groups of 8, one image per XCD
-    Div32 d_per8, d_per, d_gx;
+    Div32 d_per8, d_gx;
     int per_img, full;   // blocks per image; blocks covered by whole groups of 8 images (0: identity order)
 };
 
@@ -57,7 +57,7 @@ static void dw_block_geom(DwGeom& g, int gx, int gy, int nslice) {
     g.per_img = gx * gy;
     const unsigned long long full = (unsigned long long)(nslice / 8) * 8ull * g.per_img;
     g.full = (full * 8ull * g.per_img < (1ull << 32) && full < (1ull << 31)) ? (int)full : 0;
-    g.d_per8 = make_div32(8u * g.per_img); g.d_per = make_div32(g.per_img); g.d_gx = make_div32(gx);
+    g.d_per8 = make_div32(8u * g.per_img); g.d_gx = make_div32(gx);
 }
 
 template <int S> __host__ __device__ constexpr int dw_sw() { return S == 2 ? 2 : 4; }

@@ -366,7 +366,6 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         };
         touch(L.src); touch(L.residual);
         if (L.src < 0 && L.kind != K_STEM) { need_input_copy = true; input_last_use = i; }
-        if (L.residual == -1 && false) {}
     }
     last_use[n - 1] = n;   // final output stays live
     // depthwise -> 1x1 fusion (bf16, C <= 128): the depthwise output stays in LDS (k_dw.hip, dwp_kernel).

@@ -309,6 +309,33 @@ def test_topk_search_parity(Q, G):
     assert np.all(np.diff(s, axis=1) <= 0)
 
 
+def test_topk_search_edge_cases():
+    """Empty gallery, a gallery smaller than k (missing ranks are (-inf, -1)), identical rows (ties go to the
+    lower index, as oracle/search.py:topk_cosine orders them), k = 1 and k = 8, and a k the kernel refuses."""
+    q = fr.search.synth_rows(11, 0, 70, DEV)
+    s, i = fr.search.Matcher(q[:0], k=5).search(q)
+    assert s.shape == (70, 5) and torch.isinf(s).all() and (s < 0).all() and (i == -1).all()
+    g3 = fr.search.synth_rows(7, 0, 3, DEV)
+    s, i = fr.search.Matcher(g3, k=5).search(q)
+    assert (i[:, 3:] == -1).all() and torch.isinf(s[:, 3:]).all() and (i[:, :3] >= 0).all()
+    assert torch.equal(i[:, :3].sort(dim=1).values, torch.arange(3, device=DEV).expand(70, 3))
+    dup = q[:1].repeat(300, 1)                                            # 300 identical rows: pure tie-break
+    s, i = fr.search.Matcher(dup, k=5).search(q[:4])
+    assert torch.equal(i, torch.arange(5, device=DEV).expand(4, 5))
+    g = fr.search.synth_rows(7, 0, 5000, DEV)
+    gf = osr.bf16_bits_to_f32(g.view(torch.int16).cpu().numpy().view(np.uint16))
+    qf = osr.bf16_bits_to_f32(q.view(torch.int16).cpu().numpy().view(np.uint16))
+    for k in (1, 8):
+        s, i = fr.search.Matcher(g, k=k).search(q)
+        os_, oi, _ = osr.topk_cosine(qf, gf, k)
+        assert s.shape == (70, k) and np.abs(s.cpu().numpy() - os_).max() <= 1e-3
+        assert np.array_equal(i[:, 0].cpu().numpy(), oi[:, 0])
+    with pytest.raises(RuntimeError):
+        fr.search.Matcher(g, k=9).search(q)
+    s, i = fr.search.Matcher(g, idx_offset=1 << 33, k=5).search(q[:2])     # indices beyond 32 bits (100 M-row shards)
+    assert (i >= (1 << 33)).all()
+
+
 def test_sharded_search_equals_single(golden_x):
     """Fake-shard mode: P shards on one device, merged on the GPU, must equal
     the single-shard search exactly (deterministic tie rule)."""
