@@ -372,7 +372,7 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
     const int rowb = x.Cin * 2;
     u32x4* etile = reinterpret_cast<u32x4*>(smem);
     bf16x8 wv[NTE][KSE];
-    f32x4 bb[NTE][4];
+    f32x4 bb[NTE][4], ss[NTE][4];                     // bias and (PReLU) slopes of this lane's 16 channels per tile
     {
         const bf16x8* wef = reinterpret_cast<const bf16x8*>(smem + x.off_we) + lane;
 #pragma unroll
@@ -380,7 +380,10 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
 #pragma unroll
             for (int sk = 0; sk < KSE; ++sk) wv[t][sk] = wef[(t * KSE + sk) * 64];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bb[t][q] = *reinterpret_cast<const f32x4*>(bel + 32 * t + 16 * he + 4 * q);
+            for (int q = 0; q < 4; ++q) {
+                bb[t][q] = *reinterpret_cast<const f32x4*>(bel + 32 * t + 16 * he + 4 * q);
+                if constexpr (ACT == FR_ACT_PRELU) ss[t][q] = *reinterpret_cast<const f32x4*>(sel + 32 * t + 16 * he + 4 * q);
+            }
         }
     }
     for (int rt = wave; rt * 32 < npin; rt += 4) {
@@ -417,7 +420,14 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
 #pragma unroll
                     for (int i = 0; i < 4; ++i) r[i] = pack2bf(relu1(v.v[2 * i]), relu1(v.v[2 * i + 1]));
                 } else {
-                    if constexpr (ACT == FR_ACT_HSWISH) {
+                    if constexpr (ACT == FR_ACT_PRELU) {
+                        // slopes from registers: a pointer here makes the compiler branch and load per element
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v.v[i] = v.v[i] >= 0.f ? v.v[i] : v.v[i] * ss[t][2 * gg][i];
+                            v.v[4 + i] = v.v[4 + i] >= 0.f ? v.v[4 + i] : v.v[4 + i] * ss[t][2 * gg + 1][i];
+                        }
+                    } else if constexpr (ACT == FR_ACT_HSWISH) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v.v[j] = v.v[j] * fminf(fmaxf(v.v[j] + 3.f, 0.f), 6.f) * (1.f / 6.f);
                     } else {
@@ -497,6 +507,9 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
         if (x.act_e == FR_ACT_RELU) {
             if (border) dwp_expand<KSE, NTE, FR_ACT_RELU, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
             else dwp_expand<KSE, NTE, FR_ACT_RELU, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+        } else if (x.act_e == FR_ACT_PRELU && sel) {
+            if (border) dwp_expand<KSE, NTE, FR_ACT_PRELU, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            else dwp_expand<KSE, NTE, FR_ACT_PRELU, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
         } else if (x.act_e == FR_ACT_HSWISH) {
             if (border) dwp_expand<KSE, NTE, FR_ACT_HSWISH, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
             else dwp_expand<KSE, NTE, FR_ACT_HSWISH, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);

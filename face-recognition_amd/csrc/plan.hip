@@ -379,10 +379,9 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
             const int e_last_use = D.src >= 0 ? last_use[D.src] : -1;      // before the fused kernel extends it
             if (D.src >= 0) last_use[D.src] = std::max(last_use[D.src], i + 1);
             else if (need_input_copy) input_last_use = std::max(input_last_use, i + 1);
-            // the expand 1x1 conv in front of the depthwise conv as well (expand -> depthwise -> project): bit-identical
-            // to the separate launches but, as measured in round 1, slower than them (two blocks per CU, the MFMA
-            // epilogue of the expand phase is latency-bound) -- opt-in with FR_FUSE3=1 until that is solved
-            const bool fuse3 = getenv("FR_FUSE3") && atoi(getenv("FR_FUSE3")) != 0;
+            // the expand 1x1 conv in front of the depthwise conv as well (expand -> depthwise -> project in one
+            // launch, the 4x wider expanded activation never leaves LDS); FR_FUSE3=0 keeps the expand conv separate
+            const bool fuse3 = !(getenv("FR_FUSE3") && atoi(getenv("FR_FUSE3")) == 0);
             if (fuse3 && D.src >= 0 && D.src == i - 1) {
                 Layer& E = pl->layers[i - 1];
                 const bool se_in = E.src >= 0 && pl->layers[E.src].kind == K_SE;

@@ -133,25 +133,30 @@ def test_fused_depthwise_pointwise_equals_unfused(name, golden_x):
 
 @pytest.mark.parametrize("name", ["mobilenetv3_large", "mobilenetv3_small", "mobilenetv2"])
 def test_fused_expand_depthwise_pointwise_equals_unfused(name, golden_x, monkeypatch):
-    """FR_FUSE3=1 (opt-in) also computes the expand 1x1 conv of an inverted-residual block inside dwp_kernel:
-    same MFMA k order and the same bf16 rounding points as the three separate kernels, so bit-identical."""
+    """The expand 1x1 conv of an inverted-residual block is computed inside dwp_kernel as well (expand ->
+    depthwise -> project in one launch): same MFMA k order and the same bf16 rounding points as the three
+    separate kernels, so bit-identical -- to the unfused plan and to the plan with FR_FUSE3=0 (two-stage fusion)."""
     x = golden_x.to(DEV)
     m = product(name)
     with torch.no_grad():
         b = m(x, precision="bf16", fuse=False)
-    monkeypatch.setenv("FR_FUSE3", "1")
-    m.invalidate()                                   # plans read FR_FUSE3 when they are created
-    try:
-        with torch.no_grad():
-            a = m(x, precision="bf16", fuse=True)
-            big = m(x.repeat(5, 1, 1, 1), precision="bf16", fuse=True)
-        names = [r[1] for r in m.plan(DEV, "bf16", True).profile(x)]
-    finally:
-        m.invalidate()
+        a = m(x, precision="bf16", fuse=True)
+        big = m(x.repeat(5, 1, 1, 1), precision="bf16", fuse=True)
+    names = [r[1] for r in m.plan(DEV, "bf16", True).profile(x)]
     assert torch.equal(a, b)
     assert torch.equal(big.view(5, len(x), -1), b.unsqueeze(0).expand(5, -1, -1))
     fused = [i for i in range(2, len(names)) if names[i] == "dwp_kernel" and names[i - 1].startswith("(fused") and names[i - 2].startswith("(fused")]
     assert fused, names
+    monkeypatch.setenv("FR_FUSE3", "0")
+    m.invalidate()                                   # plans read FR_FUSE3 when they are created
+    try:
+        with torch.no_grad():
+            c = m(x, precision="bf16", fuse=True)
+        names2 = [r[1] for r in m.plan(DEV, "bf16", True).profile(x)]
+    finally:
+        m.invalidate()
+    assert torch.equal(c, b) and "dwp_kernel" in names2
+    assert not [i for i in range(2, len(names2)) if names2[i] == "dwp_kernel" and names2[i - 2].startswith("(fused")]
 
 
 @pytest.mark.parametrize("name,precision", [("mobilenetv3_small", "bf16"), ("mobilenetv3_small", "f32"), ("mobilenetv1", "bf16"),
