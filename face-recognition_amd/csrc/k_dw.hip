@@ -347,6 +347,7 @@ struct DwpArgs {
     int npx, npx_pad;     // TH*TW and its round-up to 32
     int pitch;            // bytes per row of the LDS depthwise result
     int off_wp, off_stage;
+    int off_pb;           // bias then slopes of the 1x1 conv, [NT*32] floats each
     // optional expand 1x1 conv in front (EXPAND form): dw.x is then unused
     const bf16* xin;      // block input [N,H,W,Cin]
     const bf16* we;       // expand weights packed [NTe][KSe][64][8]
@@ -464,6 +465,17 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     for (int f = wave; f < x.NT * x.KS; f += 4)
         __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)(reinterpret_cast<const u32x4*>(x.wp) + f * 64 + lane),
                                          (dw_lds_ptr_t)(smem + x.off_wp + f * 1024), 16, 0, 0);
+    // bias and slopes of the 1x1 conv go to LDS as well: read from global memory in the epilogue they cost a
+    // memory round trip per 32-pixel step that nothing hides at two to four blocks per CU
+    {
+        const int npb = x.NT * 8;
+        if (wave == 2 && lane < 2 * npb) {
+            const int which = lane >= npb, ch = (lane - which * npb) * 4;
+            const float* pb = which ? x.e.slope : x.e.bias;
+            const void* src = (pb && ch < x.e.cout) ? (const void*)(pb + ch) : a.zeros;
+            __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + x.off_pb), 16, 0, 0);
+        }
+    }
     const V8<T>* tile = reinterpret_cast<const V8<T>*>(smem);
     const float* wl = reinterpret_cast<const float*>(smem + (size_t)g.IH * IW * g.PP * sizeof(V8<T>));
     const float* bl = wl + K * K * CBV * 8;
@@ -555,6 +567,9 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     constexpr int PITCH = stage_pitch(SG * 64);
     unsigned char* stage = smem + x.off_stage + wave * 32 * PITCH;
     const bf16x8* wf = reinterpret_cast<const bf16x8*>(smem + x.off_wp) + lane;
+    EpiArgs e2 = x.e;
+    e2.bias = reinterpret_cast<const float*>(smem + x.off_pb);
+    if (x.e.slope) e2.slope = e2.bias + x.NT * 32;
     const int cout = x.e.cout;
     for (int rt = wave; rt * 32 < x.npx_pad; rt += 4) {
         const int px = rt * 32 + p;
@@ -562,13 +577,7 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
         const int gy = oy0 + (int)oy, gx = ox0 + (int)ox;
         const bool ok = px < x.npx && gy < a.Ho && gx < a.Wo;
         const long m = ((long)n * a.Ho + gy) * a.Wo + gx;
-        bf16x8 xf[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int kk = 16 * s + 8 * h;
-            xf[s] = (s < x.KS && kk < a.C) ? *reinterpret_cast<const bf16x8*>(smem + px * x.pitch + kk * 2)
-                                           : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
+        const unsigned char* xrow = smem + px * x.pitch + 16 * h;
         for (int tg = 0; tg < x.NT; tg += SG) {
 #pragma unroll
             for (int tt = 0; tt < SG; ++tt) {
@@ -577,10 +586,16 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
                     f32x16 acc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-                    for (int s = 0; s < 8; ++s)
-                        if (s < x.KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(t * x.KS + s) * 64], xf[s], acc, 0, 0, 0);
-                    epilogue_stage(acc, x.e, m, 32 * t + 16 * h, ok, stage, PITCH, p, 32 * tt + 16 * h);
+                    // run-time k loop (no guarded 8-step unroll: the early blocks have 1..5 steps and the kernel is
+                    // bound by instruction issue); the half-step beyond C of the last step reads zeros
+                    const bf16x8* wt = wf + t * x.KS * 64;
+#pragma unroll 1
+                    for (int s = 0; s < x.KS; ++s) {
+                        bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow + 32 * s);
+                        if (16 * s + 8 * h >= a.C) xf = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[s * 64], xf, acc, 0, 0, 0);
+                    }
+                    epilogue_stage(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, p, 32 * tt + 16 * h);
                 }
             }
             // write the staged [32 pixels][<= 64 channels] back: consecutive pixels of a tile row are contiguous
@@ -602,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     }
 }
 
-struct DwpPlan { int TH, TW; size_t lds; int off_wp, off_stage, npx_pad, pitch, off_we, off_in; };
+struct DwpPlan { int TH, TW; size_t lds; int off_wp, off_stage, npx_pad, pitch, off_we, off_in, off_pb; };
 
 // Tile for the fused form: all channels in one block, <= 512 work items, everything within 64 KB of LDS.
 // cin > 0: the expand 1x1 conv (cin -> C) is computed in the kernel too.
@@ -621,7 +636,10 @@ static bool dwp_pick(int k, int s, int C, int Ho, int Wo, int cout, int cin, Dwp
     double best = 1e30; bool found = false;
     const int ths[] = {4, 7, 8, 14, 16};
     const int tws[] = {4, 8, 16, 28, 32, 56};
+    int fth = 0, ftw = 0;                                 // tuning override: FR_DWP_TILE="C,cin,TH,TW" for the matching layers
+    if (const char* ov = getenv("FR_DWP_TILE")) { int c0, ci; if (sscanf(ov, "%d,%d,%d,%d", &c0, &ci, &fth, &ftw) != 4 || c0 != C || ci != cin) fth = ftw = 0; }
     for (int th : ths) for (int tw : tws) {
+        if (fth && (th != fth || tw != ftw)) continue;
         if (th - Ho >= 2 || tw - Wo >= 4) continue;
         const int items = th * (tw / sw) * CV;
         if (items > 512) continue;
@@ -634,7 +652,8 @@ static bool dwp_pick(int k, int s, int C, int Ho, int Wo, int cout, int cin, Dwp
         // the output staging tiles live behind the depthwise result, inside the (by then dead) input tile
         const size_t off_stage = align_up(dwo, 16);
         const size_t off_wp = align_up(std::max(tile, off_stage + 4 * 32 * (size_t)stage_pitch(2 * 64)), 1024);
-        const size_t off_we = off_wp + (size_t)NT * KS * 1024;
+        const size_t off_pb = off_wp + (size_t)NT * KS * 1024;
+        const size_t off_we = off_pb + (size_t)NT * 256;
         const size_t off_in = off_we + (size_t)NTe * KSe * 1024;
         const size_t lds = off_in + (cin ? align_up((size_t)(IH * IW) * cin * 2, 16) + (size_t)NTe * 256 : 0);
         if (lds > 64 * 1024) continue;
@@ -644,7 +663,7 @@ static bool dwp_pick(int k, int s, int C, int Ho, int Wo, int cout, int cin, Dwp
         cost *= (double)cdiv(Ho, th) * th * cdiv(Wo, tw) * tw / ((double)Ho * Wo);   // edge waste
         if (cost < best) {
             best = cost; found = true;
-            *out = DwpPlan{th, tw, lds, (int)off_wp, (int)off_stage, npx_pad, pitch, (int)off_we, (int)off_in};
+            *out = DwpPlan{th, tw, lds, (int)off_wp, (int)off_stage, npx_pad, pitch, (int)off_we, (int)off_in, (int)off_pb};
         }
     }
     return found;
@@ -674,7 +693,7 @@ int launch_dwp(int k, int stride, DwArgs a, const bf16* wp, const EpiArgs& e, co
     g.d_cbv = make_div32(a.CBV); g.d_iw = make_div32(g.IW); g.d_ns = make_div32(g.nstrips); g.d_tw = make_div32(a.TW);
     DwpArgs x{};
     x.dw = a; x.wp = wp; x.e = e; x.KS = cdiv(a.C, 16); x.NT = cdiv(e.cout, 32);
-    x.npx = a.TH * a.TW; x.npx_pad = pl.npx_pad; x.pitch = pl.pitch; x.off_wp = pl.off_wp; x.off_stage = pl.off_stage;
+    x.npx = a.TH * a.TW; x.npx_pad = pl.npx_pad; x.pitch = pl.pitch; x.off_wp = pl.off_wp; x.off_stage = pl.off_stage; x.off_pb = pl.off_pb;
     if (ex) {
         x.xin = ex->xin; x.we = ex->we; x.be = ex->bias; x.se = ex->slope; x.act_e = ex->act; x.Cin = ex->Cin;
         x.KSe = cdiv(ex->Cin, 16); x.NTe = cdiv(a.C, 32); x.off_we = pl.off_we; x.off_in = pl.off_in;
