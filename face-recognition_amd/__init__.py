@@ -12,8 +12,9 @@ from .inference import (get_network, load_model, get_transform, extract_features
 from . import evaluate
 from . import search
 from . import gallery
+from . import align
 
 __all__ = ["get_network", "load_model", "get_transform", "extract_features", "extract_batch_embeddings",
-           "compare_faces", "compute_similarity", "embed_images", "cosine_pairs", "evaluate", "search", "gallery",
+           "compare_faces", "compute_similarity", "embed_images", "cosine_pairs", "evaluate", "search", "gallery", "align",
            "HipBackbone", "MobileNetV1", "MobileNetV2", "mobilenet_v3_large", "mobilenet_v3_small",
            "sphere20", "sphere36", "sphere64", "default_precision"]

@@ -111,6 +111,18 @@ int fr_embed(const fr_plan* plan, const float* x, int batch, float* out,
  * in_h*in_w*3 divisible by 4; FR_ERR_UNSUPPORTED otherwise.  SURVEY.md 8(f) rank 2. */
 int fr_embed_u8(const fr_plan* plan, const unsigned char* x_nhwc, int batch, float* out,
                 void* workspace, size_t workspace_bytes, void* stream);
+/* Replaces: face_alignment (utils/face_utils.py:56-71) = cv2.warpAffine(image, M, (size, size),
+ * borderValue=0.0) with OpenCV's defaults INTER_LINEAR / BORDER_CONSTANT, for a batch of faces that may come
+ * from different source images (models/onnx_model.py:82 calls it per face).  All pointers are device
+ * pointers: images[i] -> uint8 HWC 3-channel source image i (rows packed, width*3 bytes), sizes_hw[2i..2i+1] =
+ * its height and width, inv_matrices[6i..6i+5] = the 2x3 matrix of face i ALREADY INVERTED (cv::warpAffine
+ * inverts M in double before it starts; the host layer does the same: align.invert_affine).  out: uint8
+ * [n,size,size,3], channel order as in the source.  Same fixed-point arithmetic as OpenCV 4.10 (10-bit
+ * coordinates, 5 fractional bits, 15-bit weights): integer-exact against oracle/align.py.  The landmark ->
+ * matrix step (estimate_norm, utils/face_utils.py:19-53) is host code: align.estimate_norm.
+ * SURVEY.md 8(f) rank 4. */
+int fr_align_faces(const unsigned char* const* images, const int* sizes_hw, const double* inv_matrices,
+                   int n, int out_size, unsigned char* out, void* stream);
 /* Same, and additionally writes the output of layer `tap_layer` as fp32 NCHW to tap_out
  * (parity tests of intermediate blocks; no reference counterpart beyond forward hooks). */
 int fr_embed_tap(const fr_plan* plan, const float* x, int batch, float* out,

@@ -400,3 +400,42 @@ def test_gallery_files_json_import_search_and_ids(tmp_path, golden_x):
     built = G.build_from_images(m, DEV, ["a", "b"], [(golden_x[i].permute(1, 2, 0) * 127.5 + 127.5).round().to(torch.uint8).numpy() for i in range(2)],
                                 str(tmp_path / "b"))
     assert built.rows == 2 and built.ids == ["a", "b"]
+
+
+def test_alignment_warp_bit_exact_vs_oracle():
+    """fr_align_faces (one launch for a batch of faces from images of different sizes) against oracle/align.py's
+    restatement of cv2.warpAffine's fixed-point INTER_LINEAR / BORDER_CONSTANT path (utils/face_utils.py:56-71):
+    integer arithmetic, so bit for bit.  The oracle itself is parity unpinned (cv2 is not in this image; see
+    tests/test_host.py for the properties it is held to).  Ends by embedding the aligned faces (forward_u8)."""
+    from oracle import align as oa
+    rng = np.random.default_rng(42)
+    sizes = [(250, 250), (300, 400), (112, 112), (97, 131), (480, 640), (250, 250)]
+    imgs = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+    imgs[3] = np.full((97, 131, 3), 255, np.uint8)                                        # saturated image: no overflow
+    tmpl = oa.REFERENCE_ALIGNMENT.astype(np.float64)
+    Ms = []
+    for i, (h, w) in enumerate(sizes):
+        s, th = rng.uniform(0.5, 3.0), rng.uniform(-np.pi, np.pi)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        lm = s * tmpl @ R.T + np.array([w, h]) * rng.uniform(0.0, 0.6, 2) + rng.normal(0, 2.0, (5, 2))
+        Ms.append(oa.estimate_norm(lm))
+    Ms[2] = np.array([[1, 0, 0], [0, 1, 0.0]])                                            # identity on a 112x112 image
+    Ms[5] = np.array([[0.02, 0, 5], [0, 0.02, 7.0]])                                      # 50x minification, mostly outside
+    Ms = np.stack(Ms)
+    got = fr.align.warp_faces([torch.from_numpy(a).to(DEV) for a in imgs], Ms).cpu().numpy()
+    assert got.shape == (6, 112, 112, 3)
+    for i in range(6):
+        assert np.array_equal(got[i], oa.warp_affine_u8(imgs[i], Ms[i])), i
+    assert np.array_equal(got[2], imgs[2])
+    # batched-tensor form, another output size, one face, no faces
+    batch = torch.from_numpy(np.stack([imgs[0], imgs[5]])).to(DEV)
+    g2 = fr.align.warp_faces(batch, Ms[[0, 5]], image_size=224).cpu().numpy()
+    assert np.array_equal(g2[1], oa.warp_affine_u8(imgs[5], Ms[5], 224))
+    lm0 = tmpl * 1.7 + 20.0
+    one = fr.align.face_alignment(torch.from_numpy(imgs[4]).to(DEV), lm0).cpu().numpy()
+    assert np.array_equal(one, oa.face_alignment(imgs[4], lm0))
+    assert fr.align.warp_faces([], np.zeros((0, 2, 3))).shape == (0, 112, 112, 3)
+    with pytest.raises(RuntimeError):
+        fr.align.warp_faces([torch.from_numpy(imgs[0])], Ms[:1])
+    emb = product("mobilenetv3_small").forward_u8(torch.from_numpy(got).to(DEV), precision="bf16")
+    assert emb.shape == (6, 512) and torch.isfinite(emb).all()

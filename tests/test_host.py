@@ -201,3 +201,43 @@ def test_gallery_format_roundtrip_and_validation(tmp_path):
         f.write(b"\0\0")
     with pytest.raises(ValueError):
         G.open_gallery(d)
+
+
+def test_alignment_matrix_and_oracle_warp_properties():
+    """SURVEY.md 8(f) rank 4 (utils/face_utils.py:6-71).  cv2 / scikit-image are not importable here, so the oracle
+    (oracle/align.py, parity unpinned) is held to what the algorithms guarantee by construction: the similarity fit
+    recovers a known transform, the template maps to itself, and the fixed-point warp reproduces source pixels exactly
+    wherever the sampling positions are integers (identity, integer shifts), with zeros outside the image.  The host
+    layer's batched estimate_norm must agree with the oracle's per-face restatement."""
+    from oracle import align as oa
+    rng = np.random.default_rng(0)
+    tmpl = oa.REFERENCE_ALIGNMENT.astype(np.float64)
+    assert np.allclose(oa.estimate_norm(tmpl), [[1, 0, 0], [0, 1, 0]], atol=1e-6)
+    n = 64
+    s, th, t = rng.uniform(0.4, 3.0, n), rng.uniform(-np.pi, np.pi, n), rng.uniform(-50, 300, (n, 2))
+    R = np.stack([np.stack([np.cos(th), -np.sin(th)], -1), np.stack([np.sin(th), np.cos(th)], -1)], 1)
+    lm = s[:, None, None] * np.einsum("nij,kj->nki", R, tmpl) + t[:, None, :]          # template seen through a similarity
+    M = fr.align.estimate_norm(lm)
+    back = np.einsum("nij,nkj->nki", M[:, :, :2], lm) + M[:, None, :, 2]
+    assert np.abs(back - tmpl[None]).max() < 1e-6                                       # exact data: exact recovery
+    noisy = lm + rng.normal(0, 1.5, lm.shape)
+    A = fr.align.estimate_norm(noisy)
+    B = np.stack([oa.estimate_norm(l) for l in noisy])
+    assert np.abs(A - B).max() < 1e-9
+    assert np.abs(fr.align.estimate_norm(noisy[3]) - B[3]).max() < 1e-9                 # single-face form
+    assert np.abs(fr.align.invert_affine(B) - np.stack([oa.invert_affine(b) for b in B])).max() == 0
+    with pytest.raises(AssertionError):
+        fr.align.estimate_norm(np.zeros((4, 2)))
+    with pytest.raises(AssertionError):
+        fr.align.estimate_norm(tmpl, image_size=100)
+    assert np.allclose(fr.align.estimate_norm(tmpl * (224 / 112.0), 224), [[1, 0, 0], [0, 1, 0]], atol=1e-6)
+    # the warp at integer sampling positions is a copy
+    img = rng.integers(0, 256, size=(150, 200, 3), dtype=np.uint8)
+    assert np.array_equal(oa.warp_affine_u8(img, np.array([[1, 0, 0], [0, 1, 0.0]])), img[:112, :112])
+    sh = oa.warp_affine_u8(img, np.array([[1, 0, -30], [0, 1, -20.0]]))                 # dst(x,y) = src(x+30, y+20)
+    assert np.array_equal(sh, img[20:132, 30:142])
+    out = oa.warp_affine_u8(img, np.array([[1, 0, 50], [0, 1, 60.0]]))                  # dst(x,y) = src(x-50, y-60)
+    assert not out[:60].any() and not out[:, :50].any() and np.array_equal(out[60:, 50:], img[:52, :62])
+    half = oa.warp_affine_u8(img, np.array([[1, 0, -0.5], [0, 1, 0.0]]))                # half-pixel shift: rounded mean of neighbours
+    want = (img[:112, :112].astype(np.int32) + img[:112, 1:113] + 1) >> 1
+    assert np.array_equal(half, want.astype(np.uint8))
