@@ -99,10 +99,21 @@ FR_DEV float relu1(float v) {
 
 // Activation of 8 channels with ONE uniform branch per vector (apply_act per element makes the
 // compiler emit a switch per element).
+// PReLU with the slopes in registers.  Never write `v >= 0 ? v : v * slope[j]` with `slope` a pointer: the load
+// is then conditional, and the compiler emits a compare, an exec-masked branch and a dependent load PER ELEMENT
+// (measured: 10 k of 16 k cycles per block in the fused expand phase, 10-15 % of the 1x1 kernels with PReLU).
+FR_DEV void prelu8(Vec8f& v, const f32x4& s0, const f32x4& s1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v.v[j] = v.v[j] >= 0.f ? v.v[j] : v.v[j] * s0[j];
+        v.v[4 + j] = v.v[4 + j] >= 0.f ? v.v[4 + j] : v.v[4 + j] * s1[j];
+    }
+}
+
+// slope8: 16-byte aligned, read as two vectors up front when act == FR_ACT_PRELU (unused otherwise).
 FR_DEV void act8(Vec8f& v, int act, const float* slope8) {
     if (act == FR_ACT_PRELU) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v.v[j] = v.v[j] >= 0.f ? v.v[j] : v.v[j] * slope8[j];
+        prelu8(v, *reinterpret_cast<const f32x4*>(slope8), *reinterpret_cast<const f32x4*>(slope8 + 4));
     } else if (act == FR_ACT_HSWISH) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v.v[j] = v.v[j] * fminf(fmaxf(v.v[j] + 3.f, 0.f), 6.f) * (1.f / 6.f);
@@ -197,13 +208,7 @@ FR_DEV void epilogue_store(const f32x16& acc, const EpiArgs& e, long m, int c0, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v.v[i] = acc[8 * g + i] + b0[i]; v.v[4 + i] = acc[8 * g + 4 + i] + b1[i]; }
         if (e.act == FR_ACT_PRELU) {
-            f32x4 s0 = *reinterpret_cast<const f32x4*>(e.slope + c);
-            f32x4 s1 = *reinterpret_cast<const f32x4*>(e.slope + c + 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v.v[i] = v.v[i] >= 0.f ? v.v[i] : v.v[i] * s0[i];
-                v.v[4 + i] = v.v[4 + i] >= 0.f ? v.v[4 + i] : v.v[4 + i] * s1[i];
-            }
+            prelu8(v, *reinterpret_cast<const f32x4*>(e.slope + c), *reinterpret_cast<const f32x4*>(e.slope + c + 4));
         } else if (e.act != FR_ACT_NONE) {
             act8(v, e.act, nullptr);
         }
@@ -232,13 +237,7 @@ FR_DEV void epilogue_stage(const f32x16& acc, const EpiArgs& e, long m, int c0, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v.v[i] = acc[8 * g + i] + b0[i]; v.v[4 + i] = acc[8 * g + 4 + i] + b1[i]; }
         if (e.act == FR_ACT_PRELU) {
-            f32x4 s0 = *reinterpret_cast<const f32x4*>(e.slope + c);
-            f32x4 s1 = *reinterpret_cast<const f32x4*>(e.slope + c + 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v.v[i] = v.v[i] >= 0.f ? v.v[i] : v.v[i] * s0[i];
-                v.v[4 + i] = v.v[4 + i] >= 0.f ? v.v[4 + i] : v.v[4 + i] * s1[i];
-            }
+            prelu8(v, *reinterpret_cast<const f32x4*>(e.slope + c), *reinterpret_cast<const f32x4*>(e.slope + c + 4));
         } else if (e.act != FR_ACT_NONE) {
             act8(v, e.act, nullptr);
         }

@@ -155,18 +155,17 @@ FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const f
         row += IW * PP;
         wrow += K * 2 * CBV * 4;
     }
-    float sl[8];
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
     if (a.act == FR_ACT_PRELU) {
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(bl + CBV * 8 + (0 * CBV + cv) * 4);
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(bl + CBV * 8 + (1 * CBV + cv) * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { sl[j] = s0[j]; sl[4 + j] = s1[j]; }
+        s0 = *reinterpret_cast<const f32x4*>(bl + CBV * 8 + (0 * CBV + cv) * 4);
+        s1 = *reinterpret_cast<const f32x4*>(bl + CBV * 8 + (1 * CBV + cv) * 4);
     }
 #pragma unroll
     for (int o = 0; o < SW; ++o) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[o].v[j] = acc[o][j];
-        act8(out[o], a.act, sl);
+        if (a.act == FR_ACT_PRELU) prelu8(out[o], s0, s1);
+        else act8(out[o], a.act, nullptr);
     }
 }
 
