@@ -460,7 +460,8 @@ __global__ __launch_bounds__(256) void fc_kernel(PwArgs a) {
     const int t = blockIdx.y;
     const int ks_per = (a.KS + 3) >> 2;
     const int s_begin = wave * ks_per, s_end = min(a.KS, s_begin + ks_per);
-    const TIn* xrow = reinterpret_cast<const TIn*>(a.x) + (m_ok ? m : a.M - 1) * (long)a.K;
+    const int xt = std::is_same<TIn, float>::value ? a.x_tiles : 0;      // > 0: rows are sums of xt partial rows
+    const TIn* xrow = reinterpret_cast<const TIn*>(a.x) + (m_ok ? m : a.M - 1) * (long)a.K * (xt > 0 ? xt : 1);
     const bf16x8* W = reinterpret_cast<const bf16x8*>(a.w) + (size_t)t * a.KS * NS * 64 + lane;
 
     f32x16 acc;
@@ -472,8 +473,31 @@ __global__ __launch_bounds__(256) void fc_kernel(PwArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int s = sg + j, kk = s * 16 + 8 * h;
-            if (s < s_end && kk < a.K) xf[j].load(xrow + kk, nullptr);
-            else xf[j].zero();
+            if (s < s_end && kk < a.K) {
+                if constexpr (std::is_same<TIn, float>::value) {
+                    if (xt > 0) {
+                        // fold the pooling partials here (tile order, then the 1/(H*W) scale: the arithmetic the
+                        // separate reduce launch performed), so squeeze-excite is two launches instead of three
+                        Vec8f sum;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) sum.v[i] = 0.f;
+                        for (int q = 0; q < xt; ++q) {
+                            const Vec8f v = load8(xrow + (long)q * a.K + kk);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) sum.v[i] += v.v[i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) sum.v[i] *= a.x_scale;
+                        split8(sum, xf[j].hi, xf[j].lo);
+                    } else {
+                        xf[j].load(xrow + kk, nullptr);
+                    }
+                } else {
+                    xf[j].load(xrow + kk, nullptr);
+                }
+            } else {
+                xf[j].zero();
+            }
             const int sc = s < s_end ? s : s_end - 1;
 #pragma unroll
             for (int sp = 0; sp < NS; ++sp) wf[j][sp] = W[((size_t)sc * NS + sp) * 64];

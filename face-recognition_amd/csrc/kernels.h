@@ -13,6 +13,10 @@ struct PwArgs {
     int chunk_ks;         // k-steps of W staged in LDS at a time
     int stage_off;        // set by the launcher: LDS offset of the output staging tiles
     int ntg;              // set by the launcher: n-tiles per column group (large-K kernel)
+    // fc form only: x is [M][x_tiles][K] fp32 partial sums (squeeze-excite pooling written by the depthwise
+    // kernel); the row fed to the GEMM is their sum in tile order times x_scale.  0: x is [M][K] as usual.
+    int x_tiles;
+    float x_scale;
 };
 int launch_pw(bool in_f32, bool out_f32, const PwArgs& a, hipStream_t st);
 const char* pw_kernel_name(bool in_f32, bool out_f32, int K, int cout, bool se, int HW);

@@ -416,7 +416,7 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
             static const bool se_fuse = !(getenv("FR_SE_FUSE") && atoi(getenv("FR_SE_FUSE")) == 0);
             if (se_fuse && L.kind == K_DW && L.fuse_src < 0 && i + 1 < n && pl->layers[i + 1].kind == K_SE && pl->layers[i + 1].src == i) {
                 const int T = dw_tiles_per_image(L.in_f32, L.k, L.stride, L.C, L.H, L.W);
-                if (T > 0) { L.pool_tiles = T; L.slot_partial = alloc_slot(sizes, busy, (size_t)T * L.C * 4); }
+                if (T > 0) { L.pool_tiles = T; L.slot_partial = alloc_slot(sizes, busy, (size_t)T * L.C * 4); if (T <= 8) launches -= 1; }   // <= 8 tiles: fc1 folds them, no reduce launch
             }
         }
         if (L.kind == K_SE) {
@@ -590,16 +590,21 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
                 float* pool = reinterpret_cast<float*>(base[L.slot_pool]);
                 float* hid = reinterpret_cast<float*>(base[L.slot_hidden]);
                 const Layer& D = plan->layers[L.src];
-                if (D.slot_partial >= 0) {      // pooled sums came with the depthwise output: fold the tiles, scale by 1/(H*W)
+                // pooled sums came with the depthwise output: fc1 folds up to 8 tiles per image itself (one launch
+                // fewer); more tiles than that are folded by a reduce launch first (a serial fold inside the GEMM's
+                // operand load was slower there: 0.030 vs 0.015 ms for the 28x28 layer with 49 tiles)
+                const bool partials = D.slot_partial >= 0 && D.pool_tiles <= 8;
+                if (D.slot_partial >= 0 && !partials) {
                     ReduceArgs r{base[D.slot_partial], nullptr, nullptr, pool, N, D.pool_tiles, L.C, 1.f / (float)(L.H * L.W)};
                     rc = launch_reduce(true, r, st);
-                } else {
+                } else if (!partials) {
                     ReduceArgs r{xin, nullptr, nullptr, pool, N, L.H * L.W, L.C, 0.f};
                     rc = launch_reduce(L.in_f32, r, st);
                 }
                 if (rc) break;
                 PwArgs a{};
                 a.x = pool; a.w = L.w_packed; a.se = nullptr;
+                if (partials) { a.x = base[D.slot_partial]; a.x_tiles = D.pool_tiles; a.x_scale = 1.f / (float)(L.H * L.W); }
                 a.e = EpiArgs{L.bias, nullptr, nullptr, hid, L.cout, FR_ACT_RELU};
                 a.M = N; a.K = L.K; a.KS = L.KS; a.NT = L.NT; a.HW = 1; a.chunk_ks = L.chunk_ks;
                 rc = launch_fc(true, a, st);
