@@ -563,7 +563,8 @@ static int launch_pw_stream_sg(const PwArgs& a, hipStream_t st) {
     // weight slab it staged is amortised (one 128-pixel tile per block re-staged 20 KB of weights for
     // 16 KB of activations in the 160->960 layers)
     const int ng = cdiv(a.NT, NTB);
-    const long want = std::max<long>(8, cdiv(2048, ng));
+    static const int total_blocks = getenv("FR_PW_BLOCKS") ? atoi(getenv("FR_PW_BLOCKS")) : 2048;
+    const long want = std::max<long>(8, cdiv(total_blocks, ng));
     const PwGrid pg{(int)std::min<long>(n_iter, want), ng};
     dim3 grid(pw_grid_blocks(pg.gx, pg.ng));
     size_t lds = (size_t)NTB * a.KS * 1024 + (size_t)NTB * 256;
