@@ -667,6 +667,8 @@ extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char**
                                   "fc_kernel", "conv_glds_kernel"};
     const Layer& L = plan->layers[layer];
     *name = names[L.kind];
+    if (L.kind == K_SE && L.src >= 0 && plan->layers[L.src].slot_partial >= 0 && plan->layers[L.src].pool_tiles <= 8)
+        *name = "se(2xfc_kernel)";                    // fc1 folds the depthwise kernel's pooling partials itself
     if (L.fused_next) {
         *name = "(fused into the next layer)";
     } else if (L.kind == K_PW && L.fuse_src >= 0) {
