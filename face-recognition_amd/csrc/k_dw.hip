@@ -250,9 +250,26 @@ static size_t dw_lds_bytes(bool f32, int k, int s, int TH, int TW, int CBV) {
 // Work items are strips of 4 outputs at stride 1 (each LDS read serves up to K outputs) and of 2 at
 // stride 2 (2+K columns for 2 outputs is within 10 % of a strip of 4, and the LDS-limited stride-2
 // tiles get twice the work items).
+// Measured-best tiles for the layer shapes of the four MobileNets (bf16, 512-image launches, MI355X):
+// tools/dw_probe.py sweeps (TH, TW, CBV) per shape, tools/make_dw_table.py keeps the entries that beat the cost
+// model below by at least 3 % (profiles/tuning/).  Shapes that are not listed use the cost model.
+struct DwTileEntry { int C, Ho, k, s, TH, TW, CBV; };
+static const DwTileEntry kDwTiles[] = {
+#include "dw_tiles.inc"
+};
+
 static void dw_pick_tile(bool f32, int k, int s, DwArgs& a) {
     const int CV = a.C / 8;
     const int sw = s == 2 ? 2 : 4;
+    if (!f32 && a.Ho == a.Wo) {
+        for (const DwTileEntry& e : kDwTiles)
+            if (e.C == a.C && e.Ho == a.Ho && e.k == k && e.s == s && e.TW % sw == 0 && e.CBV <= CV &&
+                e.TH * (e.TW / sw) * e.CBV <= 512 && dw_lds_bytes(false, k, s, e.TH, e.TW, e.CBV) <= 60 * 1024) {
+                a.TH = e.TH; a.TW = e.TW; a.CBV = e.CBV;
+                a.tiles_y = cdiv(a.Ho, e.TH); a.tiles_x = cdiv(a.Wo, e.TW); a.cchunks = cdiv(CV, e.CBV);
+                return;
+            }
+    }
     double best = 1e30;
     const int ths[] = {2, 4, 7, 8, 14, 16};
     const int tws[] = {4, 8, 12, 16, 28, 32, 56};
