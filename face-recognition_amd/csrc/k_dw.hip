@@ -637,6 +637,12 @@ struct DwpPlan { int TH, TW; size_t lds; int off_wp, off_stage, npx_pad, pitch, 
 
 // Tile for the fused form: all channels in one block, <= 512 work items, everything within 64 KB of LDS.
 // cin > 0: the expand 1x1 conv (cin -> C) is computed in the kernel too.
+// Measured-best tiles of the fused kernels (see kDwTiles above; tools/dwp_probe.py).
+struct DwpTileEntry { int C, cin, Ho, k, s, cout, TH, TW; };
+static const DwpTileEntry kDwpTiles[] = {
+#include "dwp_tiles.inc"
+};
+
 static bool dwp_pick(int k, int s, int C, int Ho, int Wo, int cout, int cin, DwpPlan* out) {
     const int CV = C / 8, sw = s == 2 ? 2 : 4;
     if (C % 8 || CV > 16 || C > 128 || cout % 8 || cout > 128 || (k != 3 && k != 5) || (s != 1 && s != 2)) return false;
@@ -654,6 +660,9 @@ static bool dwp_pick(int k, int s, int C, int Ho, int Wo, int cout, int cin, Dwp
     const int tws[] = {4, 8, 16, 28, 32, 56};
     int fth = 0, ftw = 0;                                 // tuning override: FR_DWP_TILE="C,cin,TH,TW" for the matching layers
     if (const char* ov = getenv("FR_DWP_TILE")) { int c0, ci; if (sscanf(ov, "%d,%d,%d,%d", &c0, &ci, &fth, &ftw) != 4 || c0 != C || ci != cin) fth = ftw = 0; }
+    if (!fth && Ho == Wo)
+        for (const DwpTileEntry& e : kDwpTiles)
+            if (e.C == C && e.cin == cin && e.Ho == Ho && e.k == k && e.s == s && e.cout == cout) { fth = e.TH; ftw = e.TW; break; }
     for (int th : ths) for (int tw : tws) {
         if (fth && (th != fth || tw != ftw)) continue;
         if (th - Ho >= 2 || tw - Wo >= 4) continue;
