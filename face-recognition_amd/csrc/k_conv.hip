@@ -316,12 +316,39 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
         __syncthreads();
     }
 
+    if constexpr (std::is_same<TOut, bf16>::value) {
+        // bf16 output leaves through LDS (both operand buffers are free after the last barrier): the MFMA layout
+        // gives every lane 16 channels of ONE pixel, i.e. isolated 32-byte pieces in global memory (PMC: 1.45x the
+        // algorithmic write bytes); staged as [128 pixels][BN couts], the block writes whole BN*2-byte row segments
+        constexpr int PITCH = BN * 2 + 16;
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-        const long m = m0 + (wn * TJ + j) * 32 + p;
+        for (int j = 0; j < TJ; ++j) {
+            const int row = (wn * TJ + j) * 32 + p;
+            const long m = m0 + row;
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
-            epilogue_store<TOut>(acc[i][j], a.e, m, nt0 * BN + (wm * TI + i) * 32 + 16 * h, m < a.M);
+            for (int i = 0; i < TI; ++i)
+                epilogue_stage(acc[i][j], a.e, m, nt0 * BN + (wm * TI + i) * 32 + 16 * h, m < a.M, smem, PITCH, row,
+                               (wm * TI + i) * 32 + 16 * h);
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 8;                                   // 16-byte chunks per staged row
+        const int cols = min(BN, a.e.cout - nt0 * BN);                 // couts of this tile that exist
+        bf16* Y = reinterpret_cast<bf16*>(a.e.y);
+        for (int c = tid; c < 128 * CPR; c += 256) {
+            const int row = c / CPR, ch = c - row * CPR;
+            const long m = m0 + row;
+            if (m < a.M && ch * 8 < cols)
+                *reinterpret_cast<u32x4*>(Y + m * (long)a.e.cout + nt0 * BN + ch * 8) =
+                    *reinterpret_cast<const u32x4*>(smem + row * PITCH + ch * 16);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const long m = m0 + (wn * TJ + j) * 32 + p;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                epilogue_store<TOut>(acc[i][j], a.e, m, nt0 * BN + (wm * TI + i) * 32 + 16 * h, m < a.M);
+        }
     }
 }
 
@@ -334,7 +361,8 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)cdiv(a.e.cout, bn));
     if constexpr (std::is_same<TIn, bf16>::value) {
         if (a.zeros) {
-            const size_t lds = 2 * (size_t)(bn + 128) * a.bk * 2;
+            size_t lds = 2 * (size_t)(bn + 128) * a.bk * 2;
+            if (std::is_same<TOut, bf16>::value) lds = std::max(lds, (size_t)128 * (bn * 2 + 16));   // output staging tile
             if (a.bk == 64) {
                 if (bn == 128) hipLaunchKernelGGL((conv_glds_kernel<TOut, 2, 2, 2, 2, 64>), grid, dim3(256), lds, st, a);
                 else hipLaunchKernelGGL((conv_glds_kernel<TOut, 2, 1, 1, 4, 64>), grid, dim3(256), lds, st, a);
