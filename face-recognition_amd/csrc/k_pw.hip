@@ -544,7 +544,11 @@ void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks) {
     // bf16, 128 < K <= 256: two n-tiles per block keep the whole weight slab (<= 32 KB) resident,
     // so the streaming kernel applies (no k-chunk restaging); the activations are re-read from L2
     // by the extra column groups.
-    const int cap = (!in_f32 && KS > 8 && KS <= 16) ? 2 : 4;
+    // measured (bf16, 512-image launches): with 3..8 k-steps four n-tiles per block lose 10-27 % against two (the
+    // 40->120/240 and 80->184/200 expansions of mobilenetv3_large); with 1-2 k-steps whole rows per block still win
+    int cap = (!in_f32 && KS > 2 && KS <= 16) ? 2 : 4;
+    static const int cap_env = getenv("FR_PW_NTB") ? atoi(getenv("FR_PW_NTB")) : 0;        // tuning: cap on n-tiles per block
+    if (cap_env > 0 && !in_f32) cap = std::min(cap, cap_env);
     int b = 1;
     while (b < NT && b < cap) b *= 2;
     int ck = 48 / (b * ns);           // <= 48 KB of LDS
@@ -556,7 +560,9 @@ void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks) {
 
 template <typename TOut, int NTB, int SG>
 static int launch_pw_stream_sg(const PwArgs& a, hipStream_t st) {
-    const int mt = a.KS <= 2 ? 4 : (a.KS <= 4 ? 2 : (a.KS <= 8 ? 1 : 0));
+    int mt = a.KS <= 2 ? 4 : (a.KS <= 4 ? 2 : (a.KS <= 8 ? 1 : 0));
+    static const int mt_env = getenv("FR_PW_MT") ? atoi(getenv("FR_PW_MT")) : 0;           // tuning: cap on pixel tiles per wave
+    if (mt_env > 0 && mt > mt_env) mt = mt_env;
     const long per_iter = 128L * (mt ? mt : 1);
     const long n_iter = (a.M + per_iter - 1) / per_iter;
     // ~2048 blocks in total: with many column groups each block walks several pixel tiles, so that the
