@@ -243,6 +243,13 @@ def main():
             if k:
                 line["roofline"]["traffic"] = int(k["hbm_bytes_per_step"] / (n_dom * parts))
                 line["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
+                # measured HBM rate of the same launches; for a kernel that fuses several layers the algorithmic
+                # bytes above are those of the unfused layer graph, so `achieved` can exceed it
+                line["roofline"]["traffic_GBps"] = round(line["roofline"]["traffic"] / (t_dom / n_dom * 1e-3) / 1e9, 1)
+        if any(r[1].startswith("(fused") for r in rows) and dom == "dwp_kernel":
+            line["roofline"]["note"] = ("dwp_kernel computes 2-3 layers per launch (expand 1x1 + depthwise + project 1x1); "
+                                        "alg_bytes_per_launch counts every fused layer's input and output as SURVEY.md 8(d) "
+                                        "defines them, the intermediate activations never reach HBM (see traffic)")
         if a.model in ALG_MB_PER_IMG:
             whole = ALG_MB_PER_IMG[a.model] * 1e6 * a.batch / (ms * 1e-3) / 1e9
             line["whole_path"] = {"bound": "hbm", "alg_MB_per_image": ALG_MB_PER_IMG[a.model], "achieved": round(whole, 1),
