@@ -103,6 +103,34 @@ def test_embeddings_vs_reference_golden_bf16(name, golden_dir, golden_x):
     assert c.min() >= COS_BAR, c
 
 
+@pytest.mark.parametrize("name,batch", [("mobilenetv3_large", 1024), ("sphere64", 512)])
+def test_baseline_batch_sizes_by_position_invariance(name, batch, golden_dir, golden_inputs, golden_x):
+    """BASELINE.json configs[1] / configs[2] at their full batch sizes, checked through a size-independent property:
+    an image's embedding does not depend on where in the batch it sits.  The batch repeats the 8 golden inputs (plus
+    3 noise images), so every repeat must equal the first occurrence BIT FOR BIT -- across the two sub-batches that
+    fr_embed runs on two streams, across workgroup tile boundaries and the XCD-aware block orders -- and the first
+    occurrences must match the reference's golden embeddings to the cosine bar.  Same for the uint8 entry point."""
+    g = np.load(os.path.join(golden_dir, f"emb_{name}.npz"))
+    m = product(name)
+    rng = np.random.default_rng(9)
+    u8 = np.concatenate([golden_inputs, rng.integers(0, 256, size=(3, 112, 112, 3), dtype=np.uint8)])      # period 11: odd against every tile size
+    P = len(u8)
+    reps = (batch + P - 1) // P
+    big_u8 = torch.from_numpy(np.ascontiguousarray(np.tile(u8, (reps, 1, 1, 1))[:batch])).to(DEV)
+    xp = torch.stack([osc.to_model_input(im) for im in u8]).to(DEV)
+    big = xp.repeat(reps, 1, 1, 1)[:batch].contiguous()
+    with torch.no_grad():
+        y = m(big, precision="bf16")
+        y8 = m.forward_u8(big_u8, precision="bf16")
+        y_small = m(xp, precision="bf16")
+    want = y[:P].repeat(reps, 1)[:batch]
+    assert torch.equal(y, want)
+    assert torch.equal(y8, y)
+    assert torch.equal(y[:P], y_small)                      # and not on the batch size either (11 images: one stream)
+    c = cos_rows(y[:8].cpu().numpy(), g["emb"])
+    assert c.min() >= COS_BAR, c
+
+
 @pytest.mark.parametrize("name", ["mobilenetv1", "mobilenetv2", "mobilenetv3_small", "mobilenetv3_large"])
 def test_bn_calibrated_weights_f32(name, golden_dir, golden_x):
     """'Trained-like' BatchNorm statistics captured from the reference (harder: real cancellation)."""
