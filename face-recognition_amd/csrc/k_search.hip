@@ -268,10 +268,17 @@ static void search_geometry(long Q, long G, int* nsplit, long* tiles_per_split, 
 
 extern "C" int fr_topk_workspace_bytes(int64_t Q, int64_t G, int k, size_t* out_bytes) {
     if (Q <= 0 || G <= 0 || k < 1 || k > SEARCH_KMAX || !out_bytes) FR_FAIL(FR_ERR_ARG, "fr_topk_workspace_bytes: bad arguments");
-    if (Q > SEARCH_QCHUNK) Q = SEARCH_QCHUNK;
-    int ns; long tps, qpad;
-    search_geometry(Q, G, &ns, &tps, &qpad);
-    *out_bytes = (size_t)ns * SEARCH_LISTS * qpad * k * 8 + 512;
+    // the chunks of one call share the workspace: a full chunk and the (shorter) last one have different split
+    // counts -- fewer query tiles mean more gallery splits -- so the size is the larger of the two
+    size_t need = 0;
+    const int64_t sizes[2] = {std::min<int64_t>(Q, SEARCH_QCHUNK), Q > SEARCH_QCHUNK ? Q % SEARCH_QCHUNK : 0};
+    for (int64_t qc : sizes) {
+        if (qc <= 0) continue;
+        int ns; long tps, qpad;
+        search_geometry(qc, G, &ns, &tps, &qpad);
+        need = std::max(need, (size_t)ns * SEARCH_LISTS * qpad * k * 8 + 512);
+    }
+    *out_bytes = need;
     return FR_OK;
 }
 

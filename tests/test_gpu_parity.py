@@ -386,6 +386,35 @@ def test_sharded_search_equals_single(golden_x):
         assert torch.equal(mi, i1) and torch.equal(ms, s1)
 
 
+def test_search_at_scale_by_properties():
+    """A gallery far beyond what the CPU oracle scores in seconds (2 M rows x 20 000 queries = two query chunks, many
+    gallery splits), checked through properties that do not depend on size: every planted query finds its planted
+    row first with a score far above the rest, scores are sorted, indices are valid and distinct, 4 shards merged == one shard bit
+    for bit, a sub-range of the queries gives the same rows, and a 4 k-row slice agrees with the oracle."""
+    G, Q, npl = 2_000_000, 20_000, 64
+    g = fr.search.synth_rows(7, 0, G, DEV, plant_seed=11, n_plant=npl, n_gallery_total=G)
+    q = fr.search.synth_rows(11, 0, Q, DEV)
+    s, i = fr.search.Matcher(g, k=5).search(q)
+    planted = torch.tensor([osr.plant_row(t, G, npl) for t in range(npl)], device=DEV)
+    assert torch.equal(i[:npl, 0], planted) and (s[:npl, 0] > 0.9).all()          # planted rows are noisy copies of the queries
+    assert (s[:, 1:] <= s[:, :-1]).all() and (i >= 0).all() and (i < G).all()
+    assert (i.sort(dim=1).values.diff(dim=1) > 0).all()                       # five distinct rows per query
+    parts = []
+    for r in range(4):
+        lo, hi = fr.search.shard_range(G, r, 4)
+        parts.append(fr.search.Matcher(g[lo:hi], idx_offset=lo, k=5).search(q))
+    ms, mi = fr.search.merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), 5)
+    assert torch.equal(mi, i) and torch.equal(ms, s)
+    s2, i2 = fr.search.Matcher(g, k=5).search(q[16000:17000])                  # other launch geometry, same answers
+    assert torch.equal(i2, i[16000:17000]) and torch.equal(s2, s[16000:17000])
+    lo = 1_000_000
+    gf = osr.bf16_bits_to_f32(g[lo:lo + 4096].view(torch.int16).cpu().numpy().view(np.uint16))
+    qf = osr.bf16_bits_to_f32(q[:32].view(torch.int16).cpu().numpy().view(np.uint16))
+    os_, oi, _ = osr.topk_cosine(qf, gf, 5)
+    ss, si = fr.search.Matcher(g[lo:lo + 4096].contiguous(), idx_offset=lo, k=5).search(q[:32])
+    assert np.abs(ss.cpu().numpy() - os_).max() <= 1e-3 and np.array_equal(si[:, 0].cpu().numpy(), oi[:, 0] + lo)
+
+
 def test_embedding_to_gallery_roundtrip(golden_x):
     """Embeddings -> normalised bf16 gallery -> each image retrieves itself at rank 1."""
     m = product("mobilenetv3_small")
