@@ -183,6 +183,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+// XCD-aware block order: workgroups go to the 8 XCDs round-robin in dispatch order and each XCD has its own
+// L2.  Dispatch slot L = (XCD k = L % 8, turn j = L / 8) works on pixel tile k * (tiles / 8) + j / ny and
+// cout tile j % ny: one XCD owns a contiguous range of pixel tiles (vertical halos of neighbouring tiles
+// meet in one L2) and runs the cout tiles of a pixel tile back to back (the pixels are fetched once, not
+// once per cout tile).  The last tiles % 8 pixel tiles keep the natural order.
+__device__ __forceinline__ void conv_tile_of_block(unsigned& pt, unsigned& nt) {
+    const unsigned gx = gridDim.x, ny = gridDim.y, per = gx >> 3, full = per * 8u * ny;
+    const unsigned L = blockIdx.x + gx * blockIdx.y;
+    if (L < full) {
+        const unsigned k = L & 7u, j = L >> 3, q = j / ny;
+        pt = k * per + q; nt = j - q * ny;
+    } else {
+        const unsigned rest = gx - 8u * per, Lt = L - full, q = Lt / rest;
+        pt = 8u * per + (Lt - q * rest); nt = q;
+    }
+}
+
 template <typename TOut, int TI, int TJ, int WM, int WN, int BK>
 __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
     constexpr int BN = 32 * TI * WM, BM = 32 * TJ * WN;
@@ -200,23 +217,8 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int p = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    // XCD-aware block order: workgroups go to the 8 XCDs round-robin in dispatch order and each XCD has its own
-    // L2.  Dispatch slot L = (XCD k = L % 8, turn j = L / 8) works on pixel tile k * (tiles / 8) + j / ny and
-    // cout tile j % ny: one XCD owns a contiguous range of pixel tiles (vertical halos of neighbouring tiles
-    // meet in one L2) and runs the cout tiles of a pixel tile back to back (the pixels are fetched once, not
-    // once per cout tile).  The last tiles % 8 pixel tiles keep the natural order.
-    unsigned pt = blockIdx.x, nt = blockIdx.y;
-    {
-        const unsigned gx = gridDim.x, ny = gridDim.y, per = gx >> 3, full = per * 8u * ny;
-        const unsigned L = blockIdx.x + gx * blockIdx.y;
-        if (L < full) {
-            const unsigned k = L & 7u, j = L >> 3, q = j / ny;
-            pt = k * per + q; nt = j - q * ny;
-        } else {
-            const unsigned rest = gx - 8u * per, Lt = L - full, q = Lt / rest;
-            pt = 8u * per + (Lt - q * rest); nt = q;
-        }
-    }
+    unsigned pt, nt;
+    conv_tile_of_block(pt, nt);
     const long m0 = (long)pt * BM;
     const int nt0 = (int)nt;
     const int chunks = a.Cin / BK;
@@ -352,6 +354,180 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
     }
 }
 
+
+// ---- 3x3, stride 1, bf16: the pixel operand is staged ONCE per 32-channel chunk and shared by the 9 taps ----
+// conv_glds_kernel fetches a [128 px][BK] activation tile per (tap, chunk) slice: nine fetches of nearly the same
+// pixels, and its L2 -> LDS fill runs at the rate the microarchitecture guide measures as the ceiling for
+// gathering rows from L2 into LDS (~28 B/clk/CU; PMC: profiles/r01_conv_pmc_*.txt), which caps a 128 x 128 tile
+// (64 flop per filled byte) near 1.1 PFLOP/s.  Fewer filled bytes per flop is the only way up.  With stride 1
+// and NHWC the tap (ky,kx) of output pixel m is input pixel m + (ky-1)*W + (kx-1) in the SAME linear order, so
+// a block stages the linear pixel range [m0 - W - 1, m0 + 128 + W + 1) of one channel chunk (128 + 2W + 2 rows
+// of 64 B, one LDS-DMA row per pixel) and every tap reads its B fragments from that range at a shifted row.
+// Pixels of that range that are not neighbours in the image (row wrap, other image, outside the tensor) are
+// never used: a lane whose tap falls outside the image reads a zero row instead (per-lane 9-bit mask).
+// Filled bytes per block and chunk: 9 x 8 KB of weights + <= 16 KB of pixels instead of 9 x (8 + 8) KB.
+// Rows are 64 B with the same XOR swizzle as above keyed on the physical row; 32 consecutive rows at any shift
+// cover every residue mod 16 within each 16-lane group of ds_read_b128, so the shifted reads stay conflict-free.
+template <typename TOut, int TI, int TJ, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a, int RB) {
+    constexpr int BN = 32 * TI * WM, BM = 32 * TJ * WN, ROWB = 64;
+    static_assert(WM * WN == 4 && BM == 128, "4 waves, 128 pixels per block");
+    constexpr int A_BYTES = BN * ROWB;                // one (tap, chunk) slice of weights
+    constexpr int GA = BN / 16 / 4;                   // weight DMA instructions per wave and slice
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int B_BYTES = RB * ROWB;                    // one chunk of the pixel range
+    unsigned char* const bbase = smem + 2 * A_BYTES;
+    const int zrow = 2 * A_BYTES + 2 * B_BYTES;       // 64 B of zeros
+
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int p = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    unsigned pt, nt;
+    conv_tile_of_block(pt, nt);
+    const long m0 = (long)pt * BM;
+    const int nt0 = (int)nt;
+    const int chunks = a.Cin >> 5;
+    const int KS = 9 * chunks;
+    const int W = a.W;
+
+    if (tid < 16) *reinterpret_cast<unsigned*>(smem + zrow + tid * 4) = 0u;
+
+    // DMA roles: one wave instruction fills 16 rows x 64 B; lane = (row sub, physical 16-B chunk pc)
+    const int sub = lane >> 2, pc = lane & 3;
+    const int lc = pc ^ ((sub >> 2) & 3);             // logical chunk this lane fetches (16 | row base, so sub decides)
+    const unsigned char* wsrc[GA];
+#pragma unroll
+    for (int j = 0; j < GA; ++j)
+        wsrc[j] = reinterpret_cast<const unsigned char*>(a.w) + ((size_t)nt0 * KS * BN + 16 * (wave + 4 * j) + sub) * ROWB + lc * 16;
+    const unsigned char* const X = reinterpret_cast<const unsigned char*>(a.x);
+    const unsigned char* const zsrc = reinterpret_cast<const unsigned char*>(a.zeros);
+    const long gbase = m0 - W - 1;                    // input pixel of row 0 of the staged range
+    const long rowbytes = (long)a.Cin * 2;
+    // piece i (16 rows) of the pixel range of channel chunk c -> buffer c & 1
+    auto stage_b = [&](int i, int c) {
+        if (16 * i < RB) {
+            const long g = gbase + 16 * i + sub;
+            const unsigned char* src = (g >= 0 && g < a.M) ? X + g * rowbytes + (long)c * 64 + lc * 16 : zsrc;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(bbase + (c & 1) * B_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+    auto stage_a = [&](int ks) {
+#pragma unroll
+        for (int j = 0; j < GA; ++j)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[j] + (long)ks * A_BYTES), (lds_ptr_t)(smem + (ks & 1) * A_BYTES + (wave + 4 * j) * 1024), 16, 0, 0);
+    };
+
+    // per-lane tap validity of the TJ pixels this lane multiplies, and their centre rows in the staged range
+    unsigned bmask[TJ];
+    int rcen[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int row = (wn * TJ + j) * 32 + p;
+        rcen[j] = row + W + 1;
+        const unsigned pix = (unsigned)m0 + (unsigned)row;        // the launcher guarantees M + 128 < 2^31
+        unsigned mask = 0;
+        if (pix < (unsigned)a.M) {
+            const unsigned hw = (unsigned)(a.H * W), r = pix % hw, oy = r / (unsigned)W, ox = r - oy * (unsigned)W;
+            unsigned bit = 1;
+            for (int ky = -1; ky <= 1; ++ky) {
+                const bool yok = (unsigned)((int)oy + ky) < (unsigned)a.H;
+                for (int kx = -1; kx <= 1; ++kx, bit <<= 1)
+                    if (yok && (unsigned)((int)ox + kx) < (unsigned)W) mask |= bit;
+            }
+        }
+        bmask[j] = mask;
+    }
+    int aoff[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) { const int row = (wm * TI + i) * 32 + p; aoff[i] = row * ROWB + ((h ^ ((row >> 2) & 3)) << 4); }
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int i = wave; 16 * i < RB; i += 4) stage_b(i, 0);
+    stage_a(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int tap = 0, chunk = 0, toff = -W - 1, kx = 0;
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) stage_a(ks + 1);
+        if (chunk + 1 < chunks) stage_b(wave + 4 * tap, chunk + 1);      // the next chunk's pixels, a ninth per tap
+        const unsigned char* ab = smem + (ks & 1) * A_BYTES;
+        const int bb = 2 * A_BYTES + (chunk & 1) * B_BYTES;
+        int baddr[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int r = rcen[j] + toff;
+            const int at = bb + r * ROWB + ((h ^ ((r >> 2) & 3)) << 4);
+            baddr[j] = ((bmask[j] >> tap) & 1u) ? at : zrow + (h << 4);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[TI], bfr[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ab + (aoff[i] ^ (s << 5)));
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(smem + (baddr[j] ^ (s << 5)));
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ++tap; ++toff;                                     // tap inner, channel chunk outer (see pack_conv_weights)
+        if (++kx == 3) { kx = 0; toff += W - 3; }
+        if (tap == 9) { tap = 0; toff = -W - 1; ++chunk; }
+    }
+
+    if constexpr (std::is_same<TOut, bf16>::value) {
+        constexpr int PITCH = BN * 2 + 16;                 // staged [128 pixels][BN couts], as in conv_glds_kernel
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int row = (wn * TJ + j) * 32 + p;
+            const long m = m0 + row;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                epilogue_stage(acc[i][j], a.e, m, nt0 * BN + (wm * TI + i) * 32 + 16 * h, m < a.M, smem, PITCH, row,
+                               (wm * TI + i) * 32 + 16 * h);
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 8;
+        const int cols = min(BN, a.e.cout - nt0 * BN);
+        bf16* Y = reinterpret_cast<bf16*>(a.e.y);
+        for (int c = tid; c < 128 * CPR; c += 256) {
+            const int row = c / CPR, ch = c - row * CPR;
+            const long m = m0 + row;
+            if (m < a.M && ch * 8 < cols)
+                *reinterpret_cast<u32x4*>(Y + m * (long)a.e.cout + nt0 * BN + ch * 8) =
+                    *reinterpret_cast<const u32x4*>(smem + row * PITCH + ch * 16);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const long m = m0 + (wn * TJ + j) * 32 + p;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                epilogue_store<TOut>(acc[i][j], a.e, m, nt0 * BN + (wm * TI + i) * 32 + 16 * h, m < a.M);
+        }
+    }
+}
+
+// rows of the staged pixel range (multiple of 16), or 0 when the shape does not take the shared-pixel kernel
+int conv_halo_rows(int ksize, int stride, int pad, int W, int bk) {
+    static const bool on = [] { const char* s = getenv("FR_CONV_HALO"); return !s || atoi(s) != 0; }();
+    if (!on || ksize != 3 || stride != 1 || pad != 1 || bk != 32) return 0;
+    const int rb = (128 + 2 * W + 2 + 15) / 16 * 16;
+    return rb <= 576 ? rb : 0;                       // 9 taps x 4 waves x 16 rows: a ninth of the range per tap
+}
+
 int conv_block_couts(int cout) { return cout >= 128 ? 128 : 64; }
 
 template <typename TIn, typename TOut>
@@ -361,6 +537,21 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)cdiv(a.e.cout, bn));
     if constexpr (std::is_same<TIn, bf16>::value) {
         if (a.zeros) {
+            if (const int rb = conv_halo_rows(a.ksize, a.stride, a.pad, a.W, a.bk)) {
+                size_t lds = 2 * (size_t)bn * 64 + 2 * (size_t)rb * 64 + 64;
+                if (std::is_same<TOut, bf16>::value) lds = std::max(lds, (size_t)128 * (bn * 2 + 16));
+                if (bn == 128) {
+                    auto k = conv_halo_kernel<TOut, 2, 2, 2, 2>;
+                    if (lds > 65536) FR_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, rb);
+                } else {
+                    auto k = conv_halo_kernel<TOut, 2, 1, 1, 4>;
+                    if (lds > 65536) FR_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, rb);
+                }
+                FR_LAUNCH_CHECK("conv_halo_kernel");
+                return FR_OK;
+            }
             size_t lds = 2 * (size_t)(bn + 128) * a.bk * 2;
             if (std::is_same<TOut, bf16>::value) lds = std::max(lds, (size_t)128 * (bn * 2 + 16));   // output staging tile
             if (a.bk == 64) {

@@ -82,6 +82,7 @@ struct ConvArgs {
 };
 int launch_conv(bool in_f32, bool out_f32, const ConvArgs& a, hipStream_t st);
 int conv_block_couts(int cout);   // couts per block tile (64 or 128): the packing granularity
+int conv_halo_rows(int ksize, int stride, int pad, int W, int bk);   // > 0: the 3x3 stride-1 shared-pixel kernel runs (needs bk 32)
 
 // ---- weighted spatial reduction: out[n][c] = sum_p x[n][p][c] * w[p][c] (+ b[c]); w NULL -> 1/P
 struct ReduceArgs {

@@ -239,6 +239,7 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
             const int cin = d.cin;
             static const int bk64_min = getenv("FR_CONV_BK64_MIN") ? atoi(getenv("FR_CONV_BK64_MIN")) : 64;   // tuning: smallest cin that uses 64-channel K slices
             L.conv_bk = (!L.in_f32 && d.cin % 64 == 0 && d.cin >= bk64_min) ? 64 : 32;
+            if (!L.in_f32 && conv_halo_rows(3, d.stride, d.pad, L.inW, 32)) L.conv_bk = 32;   // the shared-pixel kernel walks 32-channel chunks
             pack_conv_weights([&](int co, int tap, int c) { return (double)d.weight[((size_t)co * cin + c) * 9 + tap] * scale[co]; },
                               d.cout, d.cin, 9, L.in_f32 ? 2 : 1, L.conv_bk, packed);
             int rc = upload(pl, packed, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
