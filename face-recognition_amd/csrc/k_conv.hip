@@ -369,11 +369,11 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
 // Rows are 64 B with the same XOR swizzle as above keyed on the physical row; 32 consecutive rows at any shift
 // cover every residue mod 16 within each 16-lane group of ds_read_b128, so the shifted reads stay conflict-free.
 template <typename TOut, int TI, int TJ, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a, int RB) {
-    constexpr int BN = 32 * TI * WM, BM = 32 * TJ * WN, ROWB = 64;
-    static_assert(WM * WN == 4 && BM == 128, "4 waves, 128 pixels per block");
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_kernel(ConvArgs a, int RB) {
+    constexpr int NW = WM * WN, BN = 32 * TI * WM, BM = 32 * TJ * WN, ROWB = 64;
+    static_assert((NW == 4 || NW == 8) && (BM == 128 || BM == 256), "4 or 8 waves, 128 or 256 pixels per block");
     constexpr int A_BYTES = BN * ROWB;                // one (tap, chunk) slice of weights
-    constexpr int GA = BN / 16 / 4;                   // weight DMA instructions per wave and slice
+    constexpr int NA = BN / 16, GA = (NA + NW - 1) / NW;   // weight DMA instructions per slice, and per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int B_BYTES = RB * ROWB;                    // one chunk of the pixel range
     unsigned char* const bbase = smem + 2 * A_BYTES;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a, int RB) {
     const unsigned char* wsrc[GA];
 #pragma unroll
     for (int j = 0; j < GA; ++j)
-        wsrc[j] = reinterpret_cast<const unsigned char*>(a.w) + ((size_t)nt0 * KS * BN + 16 * (wave + 4 * j) + sub) * ROWB + lc * 16;
+        wsrc[j] = reinterpret_cast<const unsigned char*>(a.w) + ((size_t)nt0 * KS * BN + 16 * (wave + NW * j) + sub) * ROWB + lc * 16;
     const unsigned char* const X = reinterpret_cast<const unsigned char*>(a.x);
     const unsigned char* const zsrc = reinterpret_cast<const unsigned char*>(a.zeros);
     const long gbase = m0 - W - 1;                    // input pixel of row 0 of the staged range
@@ -414,7 +414,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a, int RB) {
     auto stage_a = [&](int ks) {
 #pragma unroll
         for (int j = 0; j < GA; ++j)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[j] + (long)ks * A_BYTES), (lds_ptr_t)(smem + (ks & 1) * A_BYTES + (wave + 4 * j) * 1024), 16, 0, 0);
+            if (NA % NW == 0 || wave + NW * j < NA)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[j] + (long)ks * A_BYTES), (lds_ptr_t)(smem + (ks & 1) * A_BYTES + (wave + NW * j) * 1024), 16, 0, 0);
     };
 
     // per-lane tap validity of the TJ pixels this lane multiplies, and their centre rows in the staged range
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a, int RB) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int i = wave; 16 * i < RB; i += 4) stage_b(i, 0);
+    for (int i = wave; 16 * i < RB; i += NW) stage_b(i, 0);
     stage_a(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a, int RB) {
 #pragma unroll 1
     for (int ks = 0; ks < KS; ++ks) {
         if (ks + 1 < KS) stage_a(ks + 1);
-        if (chunk + 1 < chunks) stage_b(wave + 4 * tap, chunk + 1);      // the next chunk's pixels, a ninth per tap
+        if (chunk + 1 < chunks) stage_b(wave + NW * tap, chunk + 1);      // the next chunk's pixels, a ninth per tap
         const unsigned char* ab = smem + (ks & 1) * A_BYTES;
         const int bb = 2 * A_BYTES + (chunk & 1) * B_BYTES;
         int baddr[TJ];
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a, int RB) {
     }
 
     if constexpr (std::is_same<TOut, bf16>::value) {
-        constexpr int PITCH = BN * 2 + 16;                 // staged [128 pixels][BN couts], as in conv_glds_kernel
+        constexpr int PITCH = BN * 2 + 16;                 // staged [BM pixels][BN couts], as in conv_glds_kernel
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int row = (wn * TJ + j) * 32 + p;
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a, int RB) {
         constexpr int CPR = BN / 8;
         const int cols = min(BN, a.e.cout - nt0 * BN);
         bf16* Y = reinterpret_cast<bf16*>(a.e.y);
-        for (int c = tid; c < 128 * CPR; c += 256) {
+        for (int c = tid; c < BM * CPR; c += 64 * NW) {
             const int row = c / CPR, ch = c - row * CPR;
             const long m = m0 + row;
             if (m < a.M && ch * 8 < cols)
@@ -538,17 +539,24 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     if constexpr (std::is_same<TIn, bf16>::value) {
         if (a.zeros) {
             if (const int rb = conv_halo_rows(a.ksize, a.stride, a.pad, a.W, a.bk)) {
-                size_t lds = 2 * (size_t)bn * 64 + 2 * (size_t)rb * 64 + 64;
-                if (std::is_same<TOut, bf16>::value) lds = std::max(lds, (size_t)128 * (bn * 2 + 16));
-                if (bn == 128) {
-                    auto k = conv_halo_kernel<TOut, 2, 2, 2, 2>;
-                    if (lds > 65536) FR_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, rb);
-                } else {
-                    auto k = conv_halo_kernel<TOut, 2, 1, 1, 4>;
-                    if (lds > 65536) FR_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, rb);
-                }
+                // pixels per block: 256 (8 waves) halves the weight bytes filled per flop; 128 (4 waves) keeps more
+                // blocks for small layers.  FR_CONV_BM = 128 | 256 forces one.
+                static const int env_bm = [] { const char* s = getenv("FR_CONV_BM"); return s ? atoi(s) : 0; }();
+                // measured (sphere64, 256-image sub-batches): 256 wins from about one block per CU upwards
+                const int bm = env_bm == 128 || env_bm == 256 ? env_bm : ((a.M + 255) / 256 * (long)grid.y >= 256 ? 256 : 128);
+                const int rbm = rb + (bm - 128);
+                dim3 g((unsigned)((a.M + bm - 1) / bm), grid.y);
+                size_t lds = 2 * (size_t)bn * 64 + 2 * (size_t)rbm * 64 + 64;
+                if (std::is_same<TOut, bf16>::value) lds = std::max(lds, (size_t)bm * (bn * 2 + 16));
+#define FR_CONV_HALO_LAUNCH(TI_, TJ_, WM_, WN_)                                                                         \
+    do {                                                                                                                \
+        auto k = conv_halo_kernel<TOut, TI_, TJ_, WM_, WN_>;                                                            \
+        if (lds > 65536) FR_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k, g, dim3(64 * WM_ * WN_), lds, st, a, rbm);                                                \
+    } while (0)
+                if (bm == 256) { if (bn == 128) FR_CONV_HALO_LAUNCH(2, 2, 2, 4); else FR_CONV_HALO_LAUNCH(2, 1, 1, 8); }
+                else { if (bn == 128) FR_CONV_HALO_LAUNCH(2, 2, 2, 2); else FR_CONV_HALO_LAUNCH(2, 1, 1, 4); }
+#undef FR_CONV_HALO_LAUNCH
                 FR_LAUNCH_CHECK("conv_halo_kernel");
                 return FR_OK;
             }
@@ -581,7 +589,7 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
 int launch_conv(bool in_f32, bool out_f32, const ConvArgs& a, hipStream_t st) {
     if (a.Cin % 32 || a.Cin % a.bk || (a.bk != 32 && a.bk != 64) || (in_f32 && a.bk != 32) || a.e.cout % 8 || a.M <= 0 || (a.ksize != 1 && a.ksize != 3))
         FR_FAIL(FR_ERR_ARG, "conv: Cin must be a multiple of 32, Cout of 8, ksize 1 or 3");
-    if (a.M + 128 >= 0x7FFFFFFFL) FR_FAIL(FR_ERR_ARG, "conv: more than 2^31 output pixels");
+    if (a.M + 256 >= 0x7FFFFFFFL) FR_FAIL(FR_ERR_ARG, "conv: more than 2^31 output pixels");
     if (in_f32 && out_f32) return launch_conv_t<float, float>(a, st);
     if (!in_f32 && !out_f32) return launch_conv_t<bf16, bf16>(a, st);
     if (!in_f32 && out_f32) return launch_conv_t<bf16, float>(a, st);

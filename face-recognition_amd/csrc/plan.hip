@@ -680,6 +680,8 @@ extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char**
         *name = pw_kernel_name(L.in_f32, L.out_f32, L.K, L.cout, se, L.H * L.W);
     } else if (L.kind == K_CONV3 && L.in_f32) {
         *name = "conv_gemm_kernel";
+    } else if (L.kind == K_CONV3 && conv_halo_rows(3, L.stride, L.pad, L.inW, L.conv_bk)) {
+        *name = "conv_halo_kernel";
     } else if (L.kind == K_LINEAR && L.via_conv) {
         *name = L.in_f32 ? "conv_gemm_kernel" : "conv_glds_kernel";
     }
