@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
 // a block stages the linear pixel range [m0 - W - 1, m0 + 128 + W + 1) of one channel chunk (128 + 2W + 2 rows
 // of 64 B, one LDS-DMA row per pixel) and every tap reads its B fragments from that range at a shifted row.
 // Pixels of that range that are not neighbours in the image (row wrap, other image, outside the tensor) are
-// never used: a lane whose tap falls outside the image reads a zero row instead (per-lane 9-bit mask).
+// never used: a lane whose tap falls outside the image reads zeros instead (per-lane 9-bit mask).
 // Filled bytes per block and chunk: 9 x 8 KB of weights + <= 16 KB of pixels instead of 9 x (8 + 8) KB.
 // Rows are 64 B with the same XOR swizzle as above keyed on the physical row; 32 consecutive rows at any shift
 // cover every residue mod 16 within each 16-lane group of ds_read_b128, so the shifted reads stay conflict-free.
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_kernel(ConvArgs a, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int B_BYTES = RB * ROWB;                    // one chunk of the pixel range
     unsigned char* const bbase = smem + 2 * A_BYTES;
-    const int zrow = 2 * A_BYTES + 2 * B_BYTES;       // 64 B of zeros
+    const int zrow = 2 * A_BYTES + 2 * B_BYTES;       // 256 B of zeros = one pass over the 64 banks (256-B aligned)
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int p = lane & 31, h = lane >> 5;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_kernel(ConvArgs a, 
     const int KS = 9 * chunks;
     const int W = a.W;
 
-    if (tid < 16) *reinterpret_cast<unsigned*>(smem + zrow + tid * 4) = 0u;
+    if (tid < 64) *reinterpret_cast<unsigned*>(smem + zrow + tid * 4) = 0u;
 
     // DMA roles: one wave instruction fills 16 rows x 64 B; lane = (row sub, physical 16-B chunk pc)
     const int sub = lane >> 2, pc = lane & 3;
@@ -466,7 +466,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_kernel(ConvArgs a, 
         for (int j = 0; j < TJ; ++j) {
             const int r = rcen[j] + toff;
             const int at = bb + r * ROWB + ((h ^ ((r >> 2) & 3)) << 4);
-            baddr[j] = ((bmask[j] >> tap) & 1u) ? at : zrow + (h << 4);
+            // a masked lane reads zeros from the SAME banks its pixel row would have used: redirecting it to one fixed
+            // address put it on top of another lane's banks (PMC: one conflict cycle per LDS instruction)
+            baddr[j] = ((bmask[j] >> tap) & 1u) ? at : zrow + (at & 255);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -525,6 +527,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_kernel(ConvArgs a, 
 int conv_halo_rows(int ksize, int stride, int pad, int W, int bk) {
     static const bool on = [] { const char* s = getenv("FR_CONV_HALO"); return !s || atoi(s) != 0; }();
     if (!on || ksize != 3 || stride != 1 || pad != 1 || bk != 32) return 0;
+    if (W < 12) return 0;      // 7x7 maps (512 channels, few pixel tiles): the per-tap kernel with 64-channel slices measured faster
     const int rb = (128 + 2 * W + 2 + 15) / 16 * 16;
     return rb <= 576 ? rb : 0;                       // 9 taps x 4 waves x 16 rows: a ninth of the range per tap
 }
@@ -546,7 +549,7 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
                 const int bm = env_bm == 128 || env_bm == 256 ? env_bm : ((a.M + 255) / 256 * (long)grid.y >= 256 ? 256 : 128);
                 const int rbm = rb + (bm - 128);
                 dim3 g((unsigned)((a.M + bm - 1) / bm), grid.y);
-                size_t lds = 2 * (size_t)bn * 64 + 2 * (size_t)rbm * 64 + 64;
+                size_t lds = 2 * (size_t)bn * 64 + 2 * (size_t)rbm * 64 + 256;
                 if (std::is_same<TOut, bf16>::value) lds = std::max(lds, (size_t)bm * (bn * 2 + 16));
 #define FR_CONV_HALO_LAUNCH(TI_, TJ_, WM_, WN_)                                                                         \
     do {                                                                                                                \
