@@ -525,8 +525,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_kernel(ConvArgs a, 
 
 // rows of the staged pixel range (multiple of 16), or 0 when the shape does not take the shared-pixel kernel
 int conv_halo_rows(int ksize, int stride, int pad, int W, int bk) {
-    static const bool on = [] { const char* s = getenv("FR_CONV_HALO"); return !s || atoi(s) != 0; }();
-    if (!on || ksize != 3 || stride != 1 || pad != 1 || bk != 32) return 0;
+    if (ksize != 3 || stride != 1 || pad != 1 || bk != 32) return 0;
     if (W < 12) return 0;      // 7x7 maps (512 channels, few pixel tiles): the per-tap kernel with 64-channel slices measured faster
     const int rb = (128 + 2 * W + 2 + 15) / 16 * 16;
     return rb <= 576 ? rb : 0;                       // 9 taps x 4 waves x 16 rows: a ninth of the range per tap
@@ -541,7 +540,7 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)cdiv(a.e.cout, bn));
     if constexpr (std::is_same<TIn, bf16>::value) {
         if (a.zeros) {
-            if (const int rb = conv_halo_rows(a.ksize, a.stride, a.pad, a.W, a.bk)) {
+            if (const int rb = a.halo ? conv_halo_rows(a.ksize, a.stride, a.pad, a.W, a.bk) : 0) {
                 // pixels per block: 256 (8 waves) halves the weight bytes filled per flop; 128 (4 waves) keeps more
                 // blocks for small layers.  FR_CONV_BM = 128 | 256 forces one.
                 static const int env_bm = [] { const char* s = getenv("FR_CONV_BM"); return s ? atoi(s) : 0; }();

@@ -38,6 +38,7 @@ struct Layer {
     int K = 0, KS = 0, NT = 0, chunk_ks = 0;       // GEMM geometry
     int K2 = 0, KS2 = 0, NT2 = 0, chunk_ks2 = 0;   // SE fc2 geometry
     int conv_bk = 32;                     // K-slice width the conv weights were packed with
+    bool conv_halo = false;               // dense 3x3 stride 1: conv_halo_kernel (FR_CONV_HALO, read when the plan is created)
     bool via_conv = false;                // Linear routed through the conv implicit-GEMM kernel
     bool fused_next = false;              // (reserved: a layer computed inside the next layer's kernel; none today)
     int fuse_src = -1;                    // 1x1 conv: index of the depthwise layer computed in its kernel (dwp_kernel)
@@ -237,9 +238,11 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
             L.kind = K_CONV3;
             std::vector<uint16_t> packed;
             const int cin = d.cin;
-            static const int bk64_min = getenv("FR_CONV_BK64_MIN") ? atoi(getenv("FR_CONV_BK64_MIN")) : 64;   // tuning: smallest cin that uses 64-channel K slices
+            const int bk64_min = getenv("FR_CONV_BK64_MIN") ? atoi(getenv("FR_CONV_BK64_MIN")) : 64;   // tuning: smallest cin that uses 64-channel K slices
+            const bool halo_on = !getenv("FR_CONV_HALO") || atoi(getenv("FR_CONV_HALO")) != 0;
             L.conv_bk = (!L.in_f32 && d.cin % 64 == 0 && d.cin >= bk64_min) ? 64 : 32;
-            if (!L.in_f32 && conv_halo_rows(3, d.stride, d.pad, L.inW, 32)) L.conv_bk = 32;   // the shared-pixel kernel walks 32-channel chunks
+            L.conv_halo = halo_on && !L.in_f32 && conv_halo_rows(3, d.stride, d.pad, L.inW, 32) > 0;
+            if (L.conv_halo) L.conv_bk = 32;                  // the shared-pixel kernel walks 32-channel chunks
             pack_conv_weights([&](int co, int tap, int c) { return (double)d.weight[((size_t)co * cin + c) * 9 + tap] * scale[co]; },
                               d.cout, d.cin, 9, L.in_f32 ? 2 : 1, L.conv_bk, packed);
             int rc = upload(pl, packed, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
@@ -536,7 +539,7 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
                 a.x = xin; a.w = L.w_packed;
                 a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act};
                 a.M = (long)N * L.H * L.W; a.H = L.inH; a.W = L.inW; a.Ho = L.H; a.Wo = L.W;
-                a.Cin = L.cin; a.ksize = 3; a.stride = L.stride; a.pad = L.pad; a.zeros = plan->zeros; a.bk = L.conv_bk;
+                a.Cin = L.cin; a.ksize = 3; a.stride = L.stride; a.pad = L.pad; a.zeros = plan->zeros; a.bk = L.conv_bk; a.halo = L.conv_halo;
                 rc = launch_conv(L.in_f32, L.out_f32, a, st);
                 break;
             }
@@ -680,7 +683,7 @@ extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char**
         *name = pw_kernel_name(L.in_f32, L.out_f32, L.K, L.cout, se, L.H * L.W);
     } else if (L.kind == K_CONV3 && L.in_f32) {
         *name = "conv_gemm_kernel";
-    } else if (L.kind == K_CONV3 && conv_halo_rows(3, L.stride, L.pad, L.inW, L.conv_bk)) {
+    } else if (L.kind == K_CONV3 && L.conv_halo) {
         *name = "conv_halo_kernel";
     } else if (L.kind == K_LINEAR && L.via_conv) {
         *name = L.in_f32 ? "conv_gemm_kernel" : "conv_glds_kernel";

@@ -187,6 +187,36 @@ def test_fused_expand_depthwise_pointwise_equals_unfused(name, golden_x, monkeyp
     assert not [i for i in range(2, len(names2)) if names2[i] == "dwp_kernel" and names2[i - 2].startswith("(fused")]
 
 
+@pytest.mark.parametrize("name,batch", [("sphere20", 8), ("sphere36", 131), ("sphere20", 300)])
+def test_shared_pixel_conv_equals_per_tap_conv(name, batch, golden_x, monkeypatch):
+    """conv_halo_kernel (one staged pixel range shared by the nine taps of a stride-1 3x3 conv) against
+    conv_glds_kernel with the same 32-channel K slices (FR_CONV_HALO=0; FR_CONV_BK64_MIN above every layer): same
+    (chunk, tap, k-step) accumulation order, so bit for bit -- at 8 images (128-pixel blocks everywhere), at 131
+    (256-pixel blocks on the large maps, 128 on the 14x14 ones, ragged last tile, both sub-batches of the two-stream
+    split) and at 300 images.  Borders, row wrap and image boundaries inside a staged range are all in play: the
+    golden faces are 8 different images repeated, and every row must equal the first occurrence of its image."""
+    x8 = golden_x.to(DEV)
+    x = x8.repeat((batch + 7) // 8, 1, 1, 1)[:batch].contiguous()
+    m = product(name)
+    monkeypatch.setenv("FR_CONV_BK64_MIN", "1000000")   # the layers that stay on conv_glds_kernel: 32-channel slices in both plans
+    m.invalidate()                                   # plans read both variables when they are created
+    with torch.no_grad():
+        a = m(x, precision="bf16")
+    names = [r[1] for r in m.plan(DEV, "bf16", True).profile(x8)]
+    assert "conv_halo_kernel" in names and "conv_glds_kernel" in names, names
+    monkeypatch.setenv("FR_CONV_HALO", "0")
+    m.invalidate()
+    try:
+        with torch.no_grad():
+            b = m(x, precision="bf16")
+        names2 = [r[1] for r in m.plan(DEV, "bf16", True).profile(x8)]
+    finally:
+        m.invalidate()
+    assert "conv_halo_kernel" not in names2
+    assert torch.equal(a, b)
+    assert torch.equal(a, a[:8].repeat((batch + 7) // 8, 1)[:batch])
+
+
 @pytest.mark.parametrize("name,precision", [("mobilenetv3_small", "bf16"), ("mobilenetv3_small", "f32"), ("mobilenetv1", "bf16"),
                                             ("sphere20", "bf16"), ("sphere20", "f32")])
 def test_uint8_input_equals_transformed_input(name, precision, golden_inputs, golden_x):
