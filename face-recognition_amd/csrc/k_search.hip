@@ -266,6 +266,7 @@ __global__ void topk_select_kernel(const float* s, const TI* idx, int nlists, lo
 #define RQ_GT 64                         // gallery rows per tile
 #define RQ_TILE_BYTES (RQ_GT * SEARCH_D * 2)
 #define RQ_LISTS 2
+#define RQ_AHEAD 2                       // k-steps of A fragments in flight ahead of the MFMAs
 
 template <int KK>
 __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
@@ -322,13 +323,25 @@ __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
     for (long tile = tile_begin; tile < tile_end; ++tile) {
         if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
         const unsigned char* tb = smem + buf * RQ_TILE_BYTES;
+        // the A fragments of k-step s + RQ_AHEAD are requested before the MFMAs of step s (left alone, the compiler
+        // reads each fragment right in front of its MFMA and waits for it: one exposed LDS latency per MFMA)
+        bf16x8 af[RQ_AHEAD + 1][2];
+#pragma unroll
+        for (int s = 0; s < RQ_AHEAD; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(tb + (abase[i] ^ (s << 5)));
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
-            bf16x8 af[2];
+            if (s + RQ_AHEAD < 32) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(tb + (abase[i] ^ (s << 5)));
+                for (int i = 0; i < 2; ++i)
+                    af[(s + RQ_AHEAD) % (RQ_AHEAD + 1)][i] = *reinterpret_cast<const bf16x8*>(tb + (abase[i] ^ ((s + RQ_AHEAD) << 5)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bq[s], acc[i], 0, 0, 0);
+            for (int i = 0; i < 2; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % (RQ_AHEAD + 1)][i], bq[s], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- selection: accumulator rows = gallery rows tile*64 + i*32 + (r&3) + 8*(r>>2) + 4h
         const long gb = tile * RQ_GT;
@@ -376,16 +389,13 @@ __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
 
 static void search_geometry_rq(long Q, long G, int* nsplit, long* tiles_per_split, long* Qpad) {
     const long qtiles = (Q + RQ_QB - 1) / RQ_QB, gtiles = (G + RQ_GT - 1) / RQ_GT;
-    long ns = (512 + qtiles - 1) / qtiles;         // >= 512 blocks: two turns of one 8-wave block per CU
+    static const long want = [] { const char* e = getenv("FR_SEARCH_BLOCKS"); return e && atol(e) > 0 ? atol(e) : 256L; }();   // tuning
+    long ns = (want + qtiles - 1) / qtiles;        // >= 256 blocks: one 8-wave block per CU (measured: 256 / 512 / 1024 -> 1324 / 1316 / 1240 TFLOP/s)
     if (ns > gtiles) ns = gtiles;
     if (ns < 1) ns = 1;
     const long tps = (gtiles + ns - 1) / ns;
     ns = (gtiles + tps - 1) / tps;
     *nsplit = (int)ns; *tiles_per_split = tps; *Qpad = qtiles * RQ_QB;
-}
-static bool search_use_rq() {
-    static const bool on = [] { const char* s = getenv("FR_SEARCH_RQ"); return !s || atoi(s) != 0; }();   // default on; 0 = search_kernel
-    return on;
 }
 
 static void search_geometry(long Q, long G, int* nsplit, long* tiles_per_split, long* Qpad) {
@@ -402,7 +412,15 @@ static void search_geometry(long Q, long G, int* nsplit, long* tiles_per_split, 
 // resident blocks every block walks the whole gallery on its own schedule and the gallery is
 // streamed from HBM once per block instead of once per XCD (65536 queries in one launch: 632
 // TFLOP/s; in chunks of 16384: 997).
-#define SEARCH_QCHUNK 16384
+static bool search_use_rq() {
+    static const bool on = [] { const char* s = getenv("FR_SEARCH_RQ"); return !s || atoi(s) != 0; }();   // default on; 0 = search_kernel
+    return on;
+}
+static long search_qchunk() {
+    static const long v = [] { const char* e = getenv("FR_SEARCH_QCHUNK"); return e && atol(e) >= 256 ? atol(e) / 256 * 256 : (search_use_rq() ? 32768L : 16384L); }();   // tuning
+    return v;
+}
+#define SEARCH_QCHUNK search_qchunk()
 
 extern "C" int fr_topk_workspace_bytes(int64_t Q, int64_t G, int k, size_t* out_bytes) {
     if (Q <= 0 || G <= 0 || k < 1 || k > SEARCH_KMAX || !out_bytes) FR_FAIL(FR_ERR_ARG, "fr_topk_workspace_bytes: bad arguments");
