@@ -346,7 +346,8 @@ def test_synthetic_rows_bit_exact():
     assert np.array_equal(q.view(torch.int16).cpu().numpy().view(np.uint16), osr.query_rows(11, 0, 33))
 
 
-@pytest.mark.parametrize("Q,G", [(64, 4096), (130, 1000), (1, 129), (257, 20011), (16384 + 130, 700)])   # last: two query chunks
+@pytest.mark.parametrize("Q,G", [(64, 4096), (130, 1000), (1, 129), (257, 20011), (511, 63), (512, 64), (16384 + 130, 700),
+                                 (32768 + 130, 700)])   # last: two query chunks of the resident-query kernel (the one before: of search_kernel)
 def test_topk_search_parity(Q, G):
     npl = min(8, Q)
     g = fr.search.synth_rows(7, 0, G, DEV, plant_seed=11, n_plant=npl, n_gallery_total=G)
