@@ -131,8 +131,8 @@ def max_over_ranks(v, dev, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="mobilenetv3_large")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
