@@ -266,7 +266,7 @@ __global__ void topk_select_kernel(const float* s, const TI* idx, int nlists, lo
 #define RQ_GT 64                         // gallery rows per tile
 #define RQ_TILE_BYTES (RQ_GT * SEARCH_D * 2)
 #define RQ_LISTS 2
-#define RQ_AHEAD 2                       // k-steps of A fragments in flight ahead of the MFMAs
+#define RQ_GRP 2                         // k-steps per group of A fragment reads (one group in flight ahead of the MFMAs)
 
 template <int KK>
 __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
@@ -318,31 +318,47 @@ __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;      // 32-bit LDS address of the tiles
     int buf = 0;
 #pragma unroll 1
     for (long tile = tile_begin; tile < tile_end; ++tile) {
         if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
-        const unsigned char* tb = smem + buf * RQ_TILE_BYTES;
-        // the A fragments of k-step s + RQ_AHEAD are requested before the MFMAs of step s (left alone, the compiler
-        // reads each fragment right in front of its MFMA and waits for it: one exposed LDS latency per MFMA)
-        bf16x8 af[RQ_AHEAD + 1][2];
+        // A fragments are read in groups of RQ_GRP k-steps, one group ahead of the MFMAs that use them.  The reads
+        // and their waits are inline asm: through the compiler, every second group waited with lgkmcnt(0) right
+        // after the NEXT group's reads had been issued (a full LDS round trip exposed per 8 MFMAs).  LDS reads
+        // return in order, so lgkmcnt(2 * RQ_GRP) = "all but the group just requested"; the wait names the
+        // fragments it releases as in/out operands, which orders the MFMAs that consume them after it.
+        u32x4 af[2][RQ_GRP][2];
+        unsigned ka[8];                                    // LDS address of k-step s: ka[s & 7] + (s >> 3) * 256 (+ 32768 for i = 1)
 #pragma unroll
-        for (int s = 0; s < RQ_AHEAD; ++s)
+        for (int j = 0; j < 8; ++j) ka[j] = lds0 + buf * RQ_TILE_BYTES + (abase[0] ^ (j << 5));
+        auto rd = [](auto SC, unsigned addr, u32x4& d0, u32x4& d1) {
+            constexpr int s_ = decltype(SC)::value;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d0) : "v"(addr), "n"((s_ >> 3) * 256) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d1) : "v"(addr), "n"((s_ >> 3) * 256 + 32768) : "memory");
+        };
+        auto group = [&](auto GC) {
+            constexpr int g = decltype(GC)::value;
+            if constexpr (g + 1 < 32 / RQ_GRP) {
+                rd(std::integral_constant<int, (g + 1) * RQ_GRP>{}, ka[((g + 1) * RQ_GRP) & 7], af[(g + 1) & 1][0][0], af[(g + 1) & 1][0][1]);
+                rd(std::integral_constant<int, (g + 1) * RQ_GRP + 1>{}, ka[((g + 1) * RQ_GRP + 1) & 7], af[(g + 1) & 1][1][0], af[(g + 1) & 1][1][1]);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[g & 1][0][0]), "+v"(af[g & 1][0][1]), "+v"(af[g & 1][1][0]), "+v"(af[g & 1][1][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[g & 1][0][0]), "+v"(af[g & 1][0][1]), "+v"(af[g & 1][1][0]), "+v"(af[g & 1][1][1]));
+            }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(tb + (abase[i] ^ (s << 5)));
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            if (s + RQ_AHEAD < 32) {
+            for (int u = 0; u < RQ_GRP; ++u)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    af[(s + RQ_AHEAD) % (RQ_AHEAD + 1)][i] = *reinterpret_cast<const bf16x8*>(tb + (abase[i] ^ ((s + RQ_AHEAD) << 5)));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % (RQ_AHEAD + 1)][i], bq[s], acc[i], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[g & 1][u][i]), bq[g * RQ_GRP + u], acc[i], 0, 0, 0);
+        };
+        static_assert(RQ_GRP == 2, "the group reads below are written for two k-steps per group");
+        rd(std::integral_constant<int, 0>{}, ka[0], af[0][0][0], af[0][0][1]);
+        rd(std::integral_constant<int, 1>{}, ka[1], af[0][1][0], af[0][1][1]);
+        group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{}); group(std::integral_constant<int, 2>{}); group(std::integral_constant<int, 3>{});
+        group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{}); group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{});
+        group(std::integral_constant<int, 8>{}); group(std::integral_constant<int, 9>{}); group(std::integral_constant<int, 10>{}); group(std::integral_constant<int, 11>{});
+        group(std::integral_constant<int, 12>{}); group(std::integral_constant<int, 13>{}); group(std::integral_constant<int, 14>{}); group(std::integral_constant<int, 15>{});
         // ---- selection: accumulator rows = gallery rows tile*64 + i*32 + (r&3) + 8*(r>>2) + 4h
         const long gb = tile * RQ_GT;
         const bool partial = gb + RQ_GT > a.G;
