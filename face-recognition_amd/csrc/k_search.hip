@@ -428,13 +428,14 @@ static void search_geometry(long Q, long G, int* nsplit, long* tiles_per_split, 
 // resident blocks every block walks the whole gallery on its own schedule and the gallery is
 // streamed from HBM once per block instead of once per XCD (65536 queries in one launch: 632
 // TFLOP/s; in chunks of 16384: 997).
+// read per call (two getenv per search, negligible next to a launch) so that a test can run both kernels in one process
 static bool search_use_rq() {
-    static const bool on = [] { const char* s = getenv("FR_SEARCH_RQ"); return !s || atoi(s) != 0; }();   // default on; 0 = search_kernel
-    return on;
+    const char* s = getenv("FR_SEARCH_RQ");              // default on; 0 = search_kernel
+    return !s || atoi(s) != 0;
 }
 static long search_qchunk() {
-    static const long v = [] { const char* e = getenv("FR_SEARCH_QCHUNK"); return e && atol(e) >= 256 ? atol(e) / 256 * 256 : (search_use_rq() ? 32768L : 16384L); }();   // tuning
-    return v;
+    const char* e = getenv("FR_SEARCH_QCHUNK");          // tuning
+    return e && atol(e) >= 256 ? atol(e) / 256 * 256 : (search_use_rq() ? 32768L : 16384L);
 }
 #define SEARCH_QCHUNK search_qchunk()
 

@@ -373,6 +373,22 @@ def test_topk_search_parity(Q, G):
     assert np.all(np.diff(s, axis=1) <= 0)
 
 
+def test_resident_query_search_equals_slice_staged_search(monkeypatch):
+    """search_rq_kernel (queries in registers, whole gallery tiles in LDS; the default) against search_kernel
+    (FR_SEARCH_RQ=0): both accumulate the 32 k-steps of a score in the same order, so scores and indices must be
+    identical bit for bit -- ragged query count over two 256-query blocks, a gallery that ends inside a tile, planted
+    near-duplicates, k = 5 and k = 8."""
+    G, Q = 50021, 300
+    g = fr.search.synth_rows(7, 0, G, DEV, plant_seed=11, n_plant=16, n_gallery_total=G)
+    q = fr.search.synth_rows(11, 0, Q, DEV)
+    for k in (5, 8):
+        monkeypatch.setenv("FR_SEARCH_RQ", "1")
+        s1, i1 = fr.search.Matcher(g, k=k).search(q)
+        monkeypatch.setenv("FR_SEARCH_RQ", "0")
+        s0, i0 = fr.search.Matcher(g, k=k).search(q)
+        assert torch.equal(i1, i0) and torch.equal(s1, s0)
+
+
 def test_topk_search_edge_cases():
     """Empty gallery, a gallery smaller than k (missing ranks are (-inf, -1)), identical rows (ties go to the
     lower index, as oracle/search.py:topk_cosine orders them), k = 1 and k = 8, and a k the kernel refuses."""
