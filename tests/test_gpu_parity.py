@@ -217,6 +217,83 @@ def test_shared_pixel_conv_equals_per_tap_conv(name, batch, golden_x, monkeypatc
     assert torch.equal(a, a[:8].repeat((batch + 7) // 8, 1)[:batch])
 
 
+class _OddConvNet(fr.models.HipBackbone):
+    """Not a reference model: dense 3x3 convs with channel counts the SphereFace nets never use (cout tiles that are
+    partly empty, cin not a multiple of 64), stride-1 layers with and without residual on 56x56 and 28x28 maps."""
+
+    def __init__(self):
+        super().__init__()
+        U = fr.models.ConvUnit
+        self.c0 = U(3, 32, 3, 2, norm=False)            # 56x56
+        self.c1 = U(32, 96, 3, 1, norm=False, bias=False)
+        self.c2 = U(96, 96, 3, 1, norm=False)           # + residual c1
+        self.c3 = U(96, 160, 3, 2, norm=False)          # 28x28
+        self.c4 = U(160, 160, 3, 1, norm=True, bias=False)   # + residual c3, folded BatchNorm
+        self.c5 = U(160, 40, 3, 1, norm=False)
+        self.fc = torch.nn.Linear(40 * 28 * 28, 64)
+        g = torch.Generator().manual_seed(5)
+        for p in self.parameters():
+            with torch.no_grad():
+                p.copy_(torch.randn(p.shape, generator=g) * (0.05 if p.dim() > 1 else 0.2))
+        bn = self.c4[1]
+        with torch.no_grad():
+            bn.running_mean.copy_(torch.randn(160, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(160, generator=g) + 0.5)
+
+    def lower(self, g):
+        a0 = self.c0.lower(g, "c0", -1)
+        a1 = self.c1.lower(g, "c1", a0)
+        a2 = self.c2.lower(g, "c2", a1, a1)
+        a3 = self.c3.lower(g, "c3", a2)
+        a4 = self.c4.lower(g, "c4", a3, a3)
+        a5 = self.c5.lower(g, "c5", a4)
+        g.add("fc", op=fr._lib.FR_OP_LINEAR, src=a5, cin=self.fc.in_features, cout=self.fc.out_features,
+              weight=self.fc.weight, bias=self.fc.bias)
+
+    def reference(self, x):
+        """Plain PyTorch fp32 of the same graph (eval-mode BatchNorm), outputs of c0..c5."""
+        outs = []
+        y0 = self.c0(x); outs.append(y0)
+        y1 = self.c1(y0); outs.append(y1)
+        y2 = self.c2(y1) + y1; outs.append(y2)
+        y3 = self.c3(y2); outs.append(y3)
+        y4 = self.c4(y3) + y3; outs.append(y4)
+        y5 = self.c5(y4); outs.append(y5)
+        return outs
+
+
+@pytest.mark.parametrize("batch", [3, 70])
+def test_dense_conv_odd_shapes_against_torch_fp32(batch, monkeypatch):
+    """conv_halo_kernel / conv_glds_kernel on shapes outside the SphereFace nets: cout 96 and 40 (64-cout tiles, the last
+    one partly empty), cout 160 (128 + 32), cin 96 / 160 (32-channel K slices only), residuals, folded BatchNorm.
+    Every conv output (fr_embed_tap, fp32 NCHW) against a plain PyTorch fp32 forward of the same graph on the CPU:
+    relative L2 error <= 2e-2 per layer (bf16 activations and weights, six layers deep; measured ~4e-3), and the
+    shared-pixel kernel bit for bit against the per-tap kernel."""
+    m = _OddConvNet().eval()
+    torch.manual_seed(batch)
+    x = torch.rand(batch, 3, 112, 112) * 2 - 1
+    with torch.no_grad():
+        want = m.reference(x)
+    m = m.to(DEV)
+    xg = x.to(DEV)
+    monkeypatch.setenv("FR_CONV_BK64_MIN", "1000000")
+    taps = {}
+    for halo in ("1", "0"):
+        monkeypatch.setenv("FR_CONV_HALO", halo)
+        m.invalidate()
+        names = [r[1] for r in m.plan(DEV, "bf16", False).profile(xg)]
+        assert ("conv_halo_kernel" in names) == (halo == "1"), names
+        with torch.no_grad():
+            taps[halo] = [m.forward_tap(xg, i, precision="bf16")[1] for i in range(6)]
+    m.invalidate()
+    for i in range(6):
+        got = taps["1"][i].cpu()
+        assert got.shape == want[i].shape
+        rel = float((got - want[i]).norm() / want[i].norm())
+        assert rel <= 2e-2, (i, rel)
+        assert torch.equal(taps["1"][i], taps["0"][i]), i
+
+
 @pytest.mark.parametrize("name,precision", [("mobilenetv3_small", "bf16"), ("mobilenetv3_small", "f32"), ("mobilenetv1", "bf16"),
                                             ("sphere20", "bf16"), ("sphere20", "f32")])
 def test_uint8_input_equals_transformed_input(name, precision, golden_inputs, golden_x):
