@@ -319,24 +319,31 @@ __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;      // 32-bit LDS address of the tiles
+    u32x4 af[2][RQ_GRP][2];
+    unsigned ka[8];                                        // LDS address of k-step s: ka[s & 7] + (s >> 3) * 256 (+ 32768 for i = 1)
+    auto rd = [](auto SC, unsigned addr, u32x4& d0, u32x4& d1) {
+        constexpr int s_ = decltype(SC)::value;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d0) : "v"(addr), "n"((s_ >> 3) * 256) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d1) : "v"(addr), "n"((s_ >> 3) * 256 + 32768) : "memory");
+    };
+    // Order of a tile: MFMAs -> wait for the next tile's DMA + barrier -> request the tile after next into the
+    // buffer just finished -> request the first A fragments of the next tile -> selection of this tile (its VALU
+    // work covers the barrier skew and the latency of those first reads) -> next tile.
+    if (tile_begin + 1 < tile_end) stage(tile_begin + 1, 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ka[j] = lds0 + (abase[0] ^ (j << 5));
+    if (tile_begin < tile_end) {
+        rd(std::integral_constant<int, 0>{}, ka[0], af[0][0][0], af[0][0][1]);
+        rd(std::integral_constant<int, 1>{}, ka[1], af[0][1][0], af[0][1][1]);
+    }
     int buf = 0;
 #pragma unroll 1
     for (long tile = tile_begin; tile < tile_end; ++tile) {
-        if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
         // A fragments are read in groups of RQ_GRP k-steps, one group ahead of the MFMAs that use them.  The reads
         // and their waits are inline asm: through the compiler, every second group waited with lgkmcnt(0) right
         // after the NEXT group's reads had been issued (a full LDS round trip exposed per 8 MFMAs).  LDS reads
         // return in order, so lgkmcnt(2 * RQ_GRP) = "all but the group just requested"; the wait names the
         // fragments it releases as in/out operands, which orders the MFMAs that consume them after it.
-        u32x4 af[2][RQ_GRP][2];
-        unsigned ka[8];                                    // LDS address of k-step s: ka[s & 7] + (s >> 3) * 256 (+ 32768 for i = 1)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ka[j] = lds0 + buf * RQ_TILE_BYTES + (abase[0] ^ (j << 5));
-        auto rd = [](auto SC, unsigned addr, u32x4& d0, u32x4& d1) {
-            constexpr int s_ = decltype(SC)::value;
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d0) : "v"(addr), "n"((s_ >> 3) * 256) : "memory");
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d1) : "v"(addr), "n"((s_ >> 3) * 256 + 32768) : "memory");
-        };
         auto group = [&](auto GC) {
             constexpr int g = decltype(GC)::value;
             if constexpr (g + 1 < 32 / RQ_GRP) {
@@ -353,12 +360,19 @@ __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[g & 1][u][i]), bq[g * RQ_GRP + u], acc[i], 0, 0, 0);
         };
         static_assert(RQ_GRP == 2, "the group reads below are written for two k-steps per group");
-        rd(std::integral_constant<int, 0>{}, ka[0], af[0][0][0], af[0][0][1]);
-        rd(std::integral_constant<int, 1>{}, ka[1], af[0][1][0], af[0][1][1]);
         group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{}); group(std::integral_constant<int, 2>{}); group(std::integral_constant<int, 3>{});
         group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{}); group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{});
         group(std::integral_constant<int, 8>{}); group(std::integral_constant<int, 9>{}); group(std::integral_constant<int, 10>{}); group(std::integral_constant<int, 11>{});
         group(std::integral_constant<int, 12>{}); group(std::integral_constant<int, 13>{}); group(std::integral_constant<int, 14>{}); group(std::integral_constant<int, 15>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's rows of the next tile have landed
+        __syncthreads();                                         // ... everyone's; and everyone is done reading this tile
+        if (tile + 2 < tile_end) stage(tile + 2, buf);
+        if (tile + 1 < tile_end) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ka[j] = lds0 + (buf ^ 1) * RQ_TILE_BYTES + (abase[0] ^ (j << 5));
+            rd(std::integral_constant<int, 0>{}, ka[0], af[0][0][0], af[0][0][1]);
+            rd(std::integral_constant<int, 1>{}, ka[1], af[0][1][0], af[0][1][1]);
+        }
         // ---- selection: accumulator rows = gallery rows tile*64 + i*32 + (r&3) + 8*(r>>2) + 4h
         const long gb = tile * RQ_GT;
         const bool partial = gb + RQ_GT > a.G;
@@ -392,8 +406,6 @@ __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         buf ^= 1;
     }
 
