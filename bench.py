@@ -1,24 +1,29 @@
 """bench.py -- embeddings/sec of the HIP embed path (BASELINE.json configs[1]: mobilenetv3_large,
-batch 1024, bf16, random-init weights, synthetic faces), one process per GPU.
+batch 1024, bf16, random-init weights, synthetic faces) and 1:N top-5 queries/sec, one process per GPU.
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" = one fr_embed pass over one resident batch (input fp32 NCHW already in HBM).  N > 1
-(launched by torch.distributed.run) runs N independent replicas -- embedding extraction shards
-trivially and has no collective -- and reports the aggregate (weak scaling).
-The JSON line also carries:
-  roofline      dominant kernel family, algorithmic bytes / measured per-layer HIP-event time
-  whole_path    the same for the whole network (17.70 MB/img)
-  cpu_baseline  the CPU oracle (PyTorch fp32 restatement of the reference) on this box's host cores
-  search        1:N top-5 queries/sec, gallery sharded over the N ranks, RCCL all-gather merge
+A "step" = one fr_embed pass over one resident batch (input fp32 NCHW already in HBM).  With N > 1 and no
+RANK in the environment, N ranks are started as a fresh child (`python -m torch.distributed.run`, 127.0.0.1
+rendezvous) BEFORE this process makes any GPU call; under torchrun (the driver's own launch line) the ranks are
+taken from the environment.  N > 1 runs N independent embedding replicas -- extraction shards trivially and
+has no collective -- and the 1:N search over a 100 M-row gallery sharded by rows across the
+ranks with one packed RCCL all-gather per 32768-query chunk (configs[4]).  The JSON line (rank 0) carries:
+  value / roofline / whole_path   configs[1] in the mode the config names (bf16); dominant kernel by HIP events
+  precision_modes                 the same config in every precision mode, "f32" being what "auto" (the product
+                                  default) resolves to for the MobileNets -- each with its own roofline
+  sphere64                        configs[2]: sphere64 batch 512 (MFMA roofline)
+  search                          configs[3] (10 M x 65536, one GPU) or configs[4] (100 M, sharded), + its CPU baseline
+  cpu_baseline                    the CPU oracle (PyTorch fp32 restatement of the reference) on this box's host cores
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,6 +33,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 MFMA_PEAK_TF = 2500.0          # dense bf16
 ALG_MB_PER_IMG = {"mobilenetv3_large": 17.70, "mobilenetv3_small": 5.74, "mobilenetv2": 26.6,
                   "mobilenetv1": 5.12, "sphere64": 19.8}     # SURVEY.md 8(d), 2 B/elem
+ALG_GFLOP_PER_IMG = {"mobilenetv3_large": 0.4292, "mobilenetv3_small": 0.1104, "mobilenetv2": 0.5754, "mobilenetv1": 0.0818,
+                     "sphere20": 4.0828, "sphere36": 7.782, "sphere64": 14.256}
+BASELINE_CONFIGS = {("mobilenetv3_large", 1024): "BASELINE.json configs[1]", ("sphere64", 512): "BASELINE.json configs[2]"}
+# When two kernel families are within 5 % of the largest time per step, the one earlier in this list is reported as
+# the dominant kernel, so that the choice does not flip on a 0.001 ms difference between runs.  Unfused kernels come
+# first: their algorithmic bytes are the bytes they really move.
+DOMINANT_PREFERENCE = ["pw_stream_kernel", "pw_gemm_kernel", "conv_halo_kernel", "dw_kernel", "pw_proj_kernel",
+                       "conv_glds_kernel", "dwp_kernel", "stem_kernel"]
 
 
 def synthetic_batch(batch, device, seed=0):
@@ -37,7 +50,7 @@ def synthetic_batch(batch, device, seed=0):
 
 def layer_alg_bytes(plan, batch):
     """Algorithmic bytes of every plan layer: (input elems + output elems) * 2 B (bf16 figures of
-    SURVEY.md 8(d); SE counts its two 1x1 convs only)."""
+    SURVEY.md 8(d), whatever the precision mode stores; SE counts its two 1x1 convs only)."""
     out = []
     for i in range(plan.n_layers):
         c, h, w = plan.dims[i]
@@ -70,6 +83,136 @@ def layer_alg_flops(plan, batch):
     return out
 
 
+def sync(dev, world):
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+
+
+def max_over_ranks(v, dev, world):
+    if not torch.distributed.is_initialized():
+        return v
+    t = torch.tensor([v], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item())
+
+
+def split_parts(batch):
+    """fr_embed cuts a batch >= FR_SPLIT_MIN (128) into FR_SPLIT_PARTS (2) sub-batches on two streams: one kernel
+    launch processes one layer of ONE sub-batch, and that is what the per-launch figures refer to."""
+    split_min = int(os.environ.get("FR_SPLIT_MIN", "128"))
+    parts = min(int(os.environ.get("FR_SPLIT_PARTS", "2")), 4)
+    return parts if (split_min > 0 and parts > 1 and batch >= split_min) else 1
+
+
+def profile_layers(fr, model, x, precision, parts, reps=5):
+    """Per-layer HIP-event timing on the launch stream (fr_embed_profile), averaged; outside any timed region."""
+    dev = x.device
+    plan = model.plan(dev, precision)
+    g = fr.models._Graph(); model.lower(g)
+    plan.descs_cio = [(int(d.cin), int(d.cout)) for d in g.descs]
+    plan.descs_ck = [(int(d.cin), int(d.cout), int(d.kernel), max(1, int(d.groups))) for d in g.descs]
+    pb = x.shape[0] // parts
+    for _ in range(3):                       # untimed: clocks and caches warm before the averaged passes
+        plan.profile(x[:pb])
+    acc = rows = None
+    for _ in range(reps):
+        rows = plan.profile(x[:pb])
+        acc = [r[2] for r in rows] if acc is None else [p + r[2] for p, r in zip(acc, rows)]
+    return plan, rows, [v / reps for v in acc], pb
+
+
+def roofline_records(model_name, batch, ms, plan, rows, ms_layer, pb, parts, layers_to_stderr=False):
+    """roofline (dominant kernel family), whole_path and kernel_families from the per-layer event times."""
+    alg = layer_alg_bytes(plan, pb)
+    flp = layer_alg_flops(plan, pb)
+    fam = {}
+    carry_b = carry_f = 0.0
+    for (name, kern, _, _), t, b, fl in zip(rows, ms_layer, alg, flp):
+        if kern.startswith("(fused"):          # computed inside the next layer's kernel: its work counts there
+            carry_b += b; carry_f += fl
+            continue
+        f = fam.setdefault(kern, [0.0, 0.0, 0, 0.0])
+        f[0] += t; f[1] += b + carry_b; f[2] += 1; f[3] += fl + carry_f
+        carry_b = carry_f = 0.0
+    t_max = max(v[0] for v in fam.values())
+    near = [k for k, v in fam.items() if v[0] >= 0.95 * t_max]
+    near.sort(key=lambda k: (DOMINANT_PREFERENCE.index(k) if k in DOMINANT_PREFERENCE else len(DOMINANT_PREFERENCE), k))
+    dom = near[0]
+    t_dom, b_dom, n_dom, f_dom = fam[dom]
+    out = {}
+    # arithmetic intensity of the dominant family against the machine balance decides the bound
+    if f_dom / b_dom > MFMA_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9):
+        ach = f_dom / (t_dom * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": n_dom * parts, "images_per_launch": pb,
+                           "avg_launch_ms": round(t_dom / n_dom, 4), "alg_flops_per_launch": int(f_dom / n_dom),
+                           "achieved": round(ach, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": None}
+    else:
+        ach = b_dom / (t_dom * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "launches_per_step": n_dom * parts, "images_per_launch": pb,
+                           "avg_launch_ms": round(t_dom / n_dom, 4), "alg_bytes_per_launch": int(b_dom / n_dom),
+                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+    tf = os.path.join(ROOT, "profiles", f"hbm_traffic_{model_name}_b{batch}_{plan.precision}.json")
+    if not os.path.exists(tf) and plan.precision == "bf16":
+        tf = os.path.join(ROOT, "profiles", f"hbm_traffic_{model_name}_b{batch}.json")       # round-1 name
+    if os.path.exists(tf):          # HBM bytes per launch from a separate rocprofv3 --pmc run (tools/hbm_traffic.py)
+        k = json.load(open(tf)).get("kernels", {}).get(dom)
+        if k:
+            r = out["roofline"]
+            r["traffic"] = int(k["hbm_bytes_per_step"] / (n_dom * parts))
+            r["traffic_source"] = os.path.relpath(tf, ROOT)
+            # measured HBM rate of the same launches; for a kernel that fuses several layers the algorithmic bytes
+            # are those of the unfused layer graph (SURVEY.md 8(d)), so `achieved` can exceed it
+            r["traffic_GBps"] = round(r["traffic"] / (t_dom / n_dom * 1e-3) / 1e9, 1)
+    if dom == "dwp_kernel":
+        out["roofline"]["note"] = ("dwp_kernel computes 2-3 layers per launch (expand 1x1 + depthwise + project 1x1): "
+                                   "alg_bytes_per_launch counts every fused layer's input and output as SURVEY.md 8(d) defines "
+                                   "them; the intermediate activations never reach HBM, so `frac` is not an HBM utilisation")
+    if model_name in ALG_MB_PER_IMG and out["roofline"]["bound"] == "hbm":
+        whole = ALG_MB_PER_IMG[model_name] * 1e6 * batch / (ms * 1e-3) / 1e9
+        out["whole_path"] = {"bound": "hbm", "alg_MB_per_image": ALG_MB_PER_IMG[model_name], "achieved": round(whole, 1),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBS, 4)}
+    elif model_name in ALG_GFLOP_PER_IMG:
+        whole = ALG_GFLOP_PER_IMG[model_name] * 1e9 * batch / (ms * 1e-3) / 1e12
+        out["whole_path"] = {"bound": "mfma", "alg_GFLOP_per_image": ALG_GFLOP_PER_IMG[model_name], "achieved": round(whole, 1),
+                             "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(whole / MFMA_PEAK_TF, 4)}
+    out["whole_path"]["launches_per_step"] = plan.lib.fr_plan_num_launches(plan.handle) * parts
+    out["whole_path"]["sum_launch_ms"] = round(sum(ms_layer) * parts, 4)
+    out["kernel_families"] = {k: {"ms": round(v[0] * parts, 4), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0,
+                                  "TFLOPs": round(v[3] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0,
+                                  "launches": v[2] * parts} for k, v in fam.items()}
+    if layers_to_stderr:
+        for (name, kern, _, _), t, b in zip(rows, ms_layer, alg):
+            print(f"{name:36s} {kern:22s} {t:8.4f} ms {b / (t * 1e-3) / 1e9 if t > 0 else 0:9.1f} GB/s", file=sys.stderr)
+    return out
+
+
+def measure_embed(fr, model, model_name, x, precision, steps, warmup, dev, world, step_fn=None, profile=True, layers=False):
+    """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks."""
+    batch = x.shape[0]
+    parts = split_parts(batch)
+    prof = profile_layers(fr, model, x, precision, parts) if profile else None
+    step = step_fn or (lambda t: model(t, precision=precision))
+    with torch.no_grad():
+        for _ in range(warmup):
+            step(x)
+        sync(dev, world)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(x)
+        sync(dev, world)
+    dt = max_over_ranks(time.perf_counter() - t0, dev, world)
+    ms = dt / steps * 1e3
+    rec = {"value": round(batch * steps * world / dt, 1), "unit": "embeddings/sec", "ms_per_step": round(ms, 4),
+           "dtype": precision, "batch": batch}
+    if prof is not None:
+        plan, rows, ms_layer, pb = prof
+        rec.update(roofline_records(model_name, batch, ms, plan, rows, ms_layer, pb, parts, layers))
+    return rec
+
+
 def cpu_baseline(model_name, seconds=15.0):
     from oracle import backbones as ob
     net = ob.seeded(model_name, 0)
@@ -89,10 +232,32 @@ def cpu_baseline(model_name, seconds=15.0):
             "batch1_value": round(m / dt1, 1), "host_cpus": os.cpu_count()}
 
 
+def search_cpu_baseline(n_gallery, seconds=8.0):
+    """fp32 chunked Q @ G^T + topk(5) with a running merge on the host cores, measured at a
+    1 M-row gallery (oracle/search.py: topk_cosine_fp32_chunked) and scaled linearly to the benchmarked gallery."""
+    from oracle import search as osr
+    G1, Qb = 1_000_000, 256
+    g = torch.randn(G1, 512)                                 # timing only: values do not matter
+    g = g / g.norm(dim=1, keepdim=True)
+    q = torch.randn(Qb, 512); q = q / q.norm(dim=1, keepdim=True)
+    osr.topk_cosine_fp32_chunked(q[:32], g[:200_000], 5)
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < seconds:
+        osr.topk_cosine_fp32_chunked(q, g, 5); n += Qb
+    dt = time.perf_counter() - t0
+    at_1m = n / dt
+    return {"value": round(at_1m * G1 / n_gallery, 3), "unit": "queries/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "measured_at_1M_rows": round(at_1m, 1),
+            "sample": f"{n} queries x 1 M-row gallery, fp32 chunked matmul + topk(5), {dt:.1f} s; the value is that rate "
+                      f"scaled linearly to {n_gallery} rows (extrapolation)"}
+
+
 def bench_search(dev, rank, world, steps, warmup, n_gallery, n_queries):
     import face_recognition_amd as fr
+    from oracle import search as osr                                    # checker only: where the planted rows are
     lo, hi = fr.search.shard_range(n_gallery, rank, world)
-    g = fr.search.synth_rows(7, lo, hi - lo, dev, plant_seed=11, n_plant=1024, n_gallery_total=n_gallery)
+    npl = 1024
+    g = fr.search.synth_rows(7, lo, hi - lo, dev, plant_seed=11, n_plant=npl, n_gallery_total=n_gallery)
     q = fr.search.synth_rows(11, 0, n_queries, dev)
     m = fr.search.ShardedMatcher(g, n_gallery, rank, world, k=5)
     for _ in range(warmup):
@@ -103,29 +268,56 @@ def bench_search(dev, rank, world, steps, warmup, n_gallery, n_queries):
         s, i = m.search(q)
     sync(dev, world)
     dt = max_over_ranks(time.perf_counter() - t0, dev, world)
-    from oracle import search as osr
-    planted_ok = all(int(i[t, 0]) == osr.plant_row(t, n_gallery, 1024) for t in range(0, min(1024, n_queries), 97))
+    nchk = min(npl, n_queries)
+    want = torch.tensor([osr.plant_row(t, n_gallery, npl) for t in range(nchk)], device=dev)
+    found = int((i[:nchk, 0] == want).sum())
+    sorted_ok = bool((s[:, 1:] <= s[:, :-1]).all())
     qps = n_queries * steps / dt
     flops = 2.0 * n_gallery * 512 * qps
+    cfg = "BASELINE.json configs[3]" if (world == 1 and n_gallery == 10_000_000) else \
+          ("BASELINE.json configs[4]" if n_gallery == 100_000_000 else "not a BASELINE.json config")
     return {"metric": "1:N top-5 queries/sec", "value": round(qps, 1), "unit": "queries/sec", "gallery_rows": n_gallery,
-            "queries": n_queries, "dim": 512, "dtype": "bf16", "n_gpus": world, "ms_per_step": round(dt / steps * 1e3, 3),
-            "planted_matches_found": bool(planted_ok),
+            "rows_per_rank": hi - lo, "queries": n_queries, "dim": 512, "dtype": "bf16", "n_gpus": world, "steps": steps,
+            "ms_per_step": round(dt / steps * 1e3, 3), "workload": cfg,
+            "exchange": "none (one shard)" if world == 1 and not torch.distributed.is_initialized() else
+                        f"one packed all_gather per {m.chunk}-query chunk, overlapped with the next chunk's search",
+            "planted_matches_found": found, "planted_matches": nchk, "scores_sorted": sorted_ok,
             "roofline": {"bound": "mfma", "achieved": round(flops / 1e12, 1), "peak": MFMA_PEAK_TF * world,
-                         "unit": "TFLOP/s", "frac": round(flops / 1e12 / (MFMA_PEAK_TF * world), 4)}}
+                         "unit": "TFLOP/s", "frac": round(flops / 1e12 / (MFMA_PEAK_TF * world), 4),
+                         "alg_flops_per_query": 2.0 * n_gallery * 512}}
 
 
-def sync(dev, world):
+def launch_ranks(n):
+    """--gpus N without a rank environment: start N ranks as a fresh child process group.  This process has made
+    no GPU call (importing torch does not initialise HIP), and it does not exec: it waits and forwards the code."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def rendezvous_only(a, rank, world):
+    """Resolve the ranks and the gallery sharding without touching a GPU kernel (runs on CPU over gloo too):
+    every rank reports (rank, its shard of the gallery); rank 0 prints them."""
+    from face_recognition_amd.search import shard_range
+    use_cuda = torch.cuda.is_available()
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+        torch.distributed.init_process_group("nccl" if use_cuda else "gloo")
+    ng = a.gallery or (10_000_000 if world == 1 else 100_000_000)
+    lo, hi = shard_range(ng, rank, world)
+    mine = torch.tensor([rank, lo, hi], dtype=torch.int64)
     if torch.distributed.is_initialized():
-        torch.distributed.barrier()
-    torch.cuda.synchronize(dev)
-
-
-def max_over_ranks(v, dev, world):
-    if not torch.distributed.is_initialized():
-        return v
-    t = torch.tensor([v], dtype=torch.float64, device=dev)
-    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    return float(t.item())
+        if use_cuda:
+            mine = mine.cuda(int(os.environ.get("LOCAL_RANK", 0)))
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        rows = [[int(v) for v in t.cpu()] for t in allr]
+        torch.distributed.destroy_process_group()
+    else:
+        rows = [[int(v) for v in mine]]
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "ranks": [r[0] for r in rows], "backend": "nccl" if use_cuda else "gloo",
+                          "search": {"gallery_rows": ng, "shards": [r[1:] for r in rows]}}), flush=True)
 
 
 def main():
@@ -135,21 +327,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="mobilenetv3_large")
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"],
+                    help="mode of the headline value; bf16 is what BASELINE.json configs[1] names")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"],
                     help="f32: normalised fp32 NCHW tensors, the reference's model(tensor) contract (default); "
                          "u8: uint8 HWC faces through fr_embed_u8 (transform fused into the stem kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true")
+    ap.add_argument("--no-modes", action="store_true", help="skip the other precision mode of the headline config")
+    ap.add_argument("--no-sphere64", action="store_true", help="skip the sphere64 batch-512 sub-record (configs[2])")
     ap.add_argument("--gallery", type=int, default=0,
                     help="1:N gallery rows in total (default: 10M on one GPU = BASELINE.json configs[3]; 100M sharded over the ranks = configs[4])")
     ap.add_argument("--queries", type=int, default=65536)
+    ap.add_argument("--search-steps", type=int, default=0, help="timed search steps (default: min(steps, 2))")
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
     ap.add_argument("--no-layer-profile", action="store_true", help="skip the per-layer event profile (roofline omitted)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="resolve ranks and gallery shards, print them and exit (no kernels; works over gloo without a GPU)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if a.rendezvous_only:
+        return rendezvous_only(a, rank, world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     dist_on = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ        # under torchrun even a single rank goes through RCCL
@@ -159,114 +361,67 @@ def main():
 
     torch.manual_seed(0)
     model = fr.get_network(a.model).to(dev).eval()
-    model.precision = a.precision
     x = synthetic_batch(a.batch, dev)
-    ms_layer = rows = plan = None
-    # fr_embed cuts a batch >= FR_SPLIT_MIN (128) into FR_SPLIT_PARTS (2) sub-batches on two streams: one kernel
-    # launch processes one layer of ONE sub-batch, and that is what the per-launch figures below refer to
-    split_min = int(os.environ.get("FR_SPLIT_MIN", "128"))
-    parts = min(int(os.environ.get("FR_SPLIT_PARTS", "2")), 4)
-    parts = parts if (split_min > 0 and parts > 1 and a.batch >= split_min) else 1
-    pb = a.batch // parts
-    if rank == 0 and not a.no_layer_profile:
-        # ---- per-layer HIP-event timing on the launch stream (5 profiled passes, averaged); runs before the
-        # warm-up, outside the timed region
-        plan = model.plan(dev)
-        g = fr.models._Graph(); model.lower(g)
-        plan.descs_cio = [(int(d.cin), int(d.cout)) for d in g.descs]
-        plan.descs_ck = [(int(d.cin), int(d.cout), int(d.kernel), max(1, int(d.groups))) for d in g.descs]
-        reps = 5
-        acc = None
-        for _ in range(3):                       # untimed: clocks and caches warm before the averaged passes
-            plan.profile(x[:pb])
-        for _ in range(reps):
-            rows = plan.profile(x[:pb])
-            acc = [r[2] for r in rows] if acc is None else [p + r[2] for p, r in zip(acc, rows)]
-        ms_layer = [v / reps for v in acc]
+    step_fn = None
+    xin = x
     if a.input == "u8":
         xin = ((x * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
-        step = model.forward_u8
-    else:
-        xin, step = x, model
-    with torch.no_grad():
-        for _ in range(a.warmup):
-            y = step(xin)
-        sync(dev, world)
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            y = step(xin)
-        sync(dev, world)
-    dt = max_over_ranks(time.perf_counter() - t0, dev, world)
-    ms = dt / a.steps * 1e3
-    value = a.batch * a.steps * world / dt
+        step_fn = lambda t: model.forward_u8(t, precision=a.precision)
+    prof = rank == 0 and not a.no_layer_profile
+    if prof and a.input == "u8":
+        head_prof = profile_layers(fr, model, x, a.precision, split_parts(a.batch))
+    head = measure_embed(fr, model, a.model, xin, a.precision, a.steps, a.warmup, dev, world, step_fn,
+                         profile=prof and a.input != "u8", layers=a.layers)
+    if prof and a.input == "u8":
+        plan, rows, ms_layer, pb = head_prof
+        head.update(roofline_records(a.model, a.batch, head["ms_per_step"], plan, rows, ms_layer, pb, split_parts(a.batch), a.layers))
 
-    cfg_name = {("mobilenetv3_large", 1024): "BASELINE.json configs[1]", ("sphere64", 512): "BASELINE.json configs[2]"}.get(
-        (a.model, a.batch), "not a BASELINE.json config")
-    line = {"metric": "embeddings/sec", "value": round(value, 1), "unit": "embeddings/sec", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+    cfg_name = BASELINE_CONFIGS.get((a.model, a.batch), "not a BASELINE.json config")
+    line = {"metric": "embeddings/sec", "value": head["value"], "unit": "embeddings/sec", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": f"{a.model} batch-{a.batch} {a.precision} embedding extraction, 112x112 synthetic faces"
                                    f"{' (uint8 HWC input, transform in the stem kernel)' if a.input == 'u8' else ''}, "
                                    f"random-init weights ({cfg_name})",
                        "global_batch": a.batch * world, "parallelism": f"replicas x{world} (no collective)"}}
+    for k in ("roofline", "whole_path", "kernel_families"):
+        if k in head:
+            line[k] = head[k]
 
-    if rank == 0 and ms_layer is not None:
-        alg = layer_alg_bytes(plan, pb)
-        flp = layer_alg_flops(plan, pb)
-        fam = {}
-        carry_b = carry_f = 0.0
-        for (name, kern, _, _), t, b, fl in zip(rows, ms_layer, alg, flp):
-            if kern.startswith("(fused"):          # computed inside the next layer's kernel: its work counts there
-                carry_b += b; carry_f += fl
-                continue
-            f = fam.setdefault(kern, [0.0, 0.0, 0, 0.0])
-            f[0] += t; f[1] += b + carry_b; f[2] += 1; f[3] += fl + carry_f
-            carry_b = carry_f = 0.0
-        dom = max(fam, key=lambda k: fam[k][0])
-        t_dom, b_dom, n_dom, f_dom = fam[dom]
-        # arithmetic intensity of the dominant family against the machine balance decides the bound
-        if f_dom / b_dom > MFMA_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9):
-            ach = f_dom / (t_dom * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": n_dom * parts, "images_per_launch": pb,
-                                "avg_launch_ms": round(t_dom / n_dom, 4), "alg_flops_per_launch": int(f_dom / n_dom),
-                                "achieved": round(ach, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
-                                "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": None}
-        else:
-            ach = b_dom / (t_dom * 1e-3) / 1e9
-            line["roofline"] = {"bound": "hbm", "kernel": dom, "launches_per_step": n_dom * parts, "images_per_launch": pb,
-                                "avg_launch_ms": round(t_dom / n_dom, 4), "alg_bytes_per_launch": int(b_dom / n_dom),
-                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-        tf = os.path.join(ROOT, "profiles", f"hbm_traffic_{a.model}_b{a.batch}.json")
-        if os.path.exists(tf):          # HBM bytes per launch from a separate rocprofv3 --pmc run (tools/hbm_traffic.py)
-            k = json.load(open(tf)).get("kernels", {}).get(dom)
-            if k:
-                line["roofline"]["traffic"] = int(k["hbm_bytes_per_step"] / (n_dom * parts))
-                line["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
-                # measured HBM rate of the same launches; for a kernel that fuses several layers the algorithmic
-                # bytes above are those of the unfused layer graph, so `achieved` can exceed it
-                line["roofline"]["traffic_GBps"] = round(line["roofline"]["traffic"] / (t_dom / n_dom * 1e-3) / 1e9, 1)
-        if any(r[1].startswith("(fused") for r in rows) and dom == "dwp_kernel":
-            line["roofline"]["note"] = ("dwp_kernel computes 2-3 layers per launch (expand 1x1 + depthwise + project 1x1); "
-                                        "alg_bytes_per_launch counts every fused layer's input and output as SURVEY.md 8(d) "
-                                        "defines them, the intermediate activations never reach HBM (see traffic)")
-        if a.model in ALG_MB_PER_IMG:
-            whole = ALG_MB_PER_IMG[a.model] * 1e6 * a.batch / (ms * 1e-3) / 1e9
-            line["whole_path"] = {"bound": "hbm", "alg_MB_per_image": ALG_MB_PER_IMG[a.model], "achieved": round(whole, 1),
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBS, 4),
-                                  "launches_per_step": plan.lib.fr_plan_num_launches(plan.handle) * parts,
-                                  "sum_launch_ms": round(sum(ms_layer) * parts, 4)}
-        line["kernel_families"] = {k: {"ms": round(v[0] * parts, 4), "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0,
-                                        "TFLOPs": round(v[3] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0,
-                                        "launches": v[2] * parts} for k, v in fam.items()}
-        if a.layers:
-            for (name, kern, _, _), t, b in zip(rows, ms_layer, alg):
-                print(f"{name:36s} {kern:22s} {t:8.4f} ms {b / (t * 1e-3) / 1e9 if t > 0 else 0:9.1f} GB/s", file=sys.stderr)
+    if rank == 0 and world == 1 and not a.no_modes:
+        # the same config in both precision modes.  "auto" (what load_model() -> model(x) runs when nobody chooses)
+        # resolves to f32 for the MobileNets: the mode that meets cos >= 0.9999 on raw-init AND on BN-calibrated
+        # weights (tests/test_gpu_parity.py::test_default_precision_meets_the_bar_on_every_backbone)
+        other = "f32" if a.precision == "bf16" else "bf16"
+        o = measure_embed(fr, model, a.model, x, other, max(5, a.steps // 2), max(2, a.warmup // 2), dev, 1)
+        model.invalidate()
+        mine = {k: head[k] for k in ("value", "ms_per_step", "roofline", "whole_path") if k in head}
+        theirs = {k: o[k] for k in ("value", "ms_per_step", "roofline", "whole_path", "kernel_families") if k in o}
+        line["precision_modes"] = {a.precision: mine, other: theirs, "product_default": f"auto -> {model.auto_precision}",
+                                   "parity": "bf16 meets cos >= 0.9999 on this config's random-init weights only; f32 (fp32 "
+                                             "activations, split-bf16 operands, 3 MFMA passes) meets it on every backbone, raw and BN-calibrated"}
+    del x, xin, model
+    torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not a.no_sphere64 and (a.model, a.batch) != ("sphere64", 512):
+        torch.manual_seed(0)
+        s64 = fr.get_network("sphere64").to(dev).eval()
+        xs = synthetic_batch(512, dev)
+        rec = measure_embed(fr, s64, "sphere64", xs, "bf16", max(5, a.steps // 2), max(2, a.warmup // 2), dev, 1,
+                            profile=not a.no_layer_profile)
+        rec["workload"] = "sphere64 batch-512 bf16 embedding extraction, random-init weights (BASELINE.json configs[2])"
+        line["sphere64"] = rec
+        s64.invalidate()
+        del s64, xs
+        torch.cuda.empty_cache()
 
     if not a.no_search:
         ng = a.gallery or (10_000_000 if world == 1 else 100_000_000)
-        res = bench_search(dev, rank, world, max(1, min(a.steps, 2)), 1, ng, a.queries)
+        ssteps = a.search_steps or max(1, min(a.steps, 2))
+        res = bench_search(dev, rank, world, ssteps, 1, ng, a.queries)
         if rank == 0:
+            if world == 1 and not a.no_cpu_baseline:
+                res["cpu_baseline"] = search_cpu_baseline(ng)
             line["search"] = res
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(a.model)

@@ -57,6 +57,7 @@ _SIGS = {
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fr_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
+    "fr_topk_merge_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 

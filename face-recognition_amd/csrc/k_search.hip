@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void search_kernel(SearchArgs a) {
 // out[q] = best k of nlists candidate lists (each k long, list stride `lstride` elements),
 // ordered by (score desc, index asc).  One thread per query.
 template <typename TI>
-__global__ void topk_select_kernel(const float* s, const TI* idx, int nlists, long lstride, long Q, int k,
+__global__ void topk_select_kernel(const float* s, const TI* idx, int nlists, long lstride, long lstride_i, long Q, int k,
                                    long idx_offset, float* out_s, int64_t* out_i) {
     const long q = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (q >= Q) return;
@@ -233,7 +233,7 @@ __global__ void topk_select_kernel(const float* s, const TI* idx, int nlists, lo
     for (int l = 0; l < nlists; ++l) {
         for (int c = 0; c < k; ++c) {
             float v = s[l * lstride + q * k + c];
-            int64_t vi = (int64_t)idx[l * lstride + q * k + c];
+            int64_t vi = (int64_t)idx[l * lstride_i + q * k + c];
             if (vi == (int64_t)0x7FFFFFFF && sizeof(TI) == 4) continue;        // empty slot
 #pragma unroll
             for (int e = 0; e < SEARCH_KMAX; ++e) {
@@ -415,6 +415,28 @@ __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
         if (e < a.k) { a.part_s[base + e] = ts[e]; a.part_i[base + e] = ti[e]; }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it once for each device a
+// search runs on (a process-wide flag made the first search on a second GPU fail at launch), under a lock so that
+// host threads searching on different streams do not race on the flags.
+#include <mutex>
+static int search_set_lds_limits() {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    int dev = 0;
+    FR_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && done[dev]) return FR_OK;
+    const int rq = 2 * RQ_TILE_BYTES, sl = 2 * S_BUF + S_PAD;
+    FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_rq_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, rq));
+    FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_rq_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, rq));
+    FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_rq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, rq));
+    FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
+    FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
+    FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
+    if (dev >= 0 && dev < 64) done[dev] = true;
+    return FR_OK;
+}
+
 static void search_geometry_rq(long Q, long G, int* nsplit, long* tiles_per_split, long* Qpad) {
     const long qtiles = (Q + RQ_QB - 1) / RQ_QB, gtiles = (G + RQ_GT - 1) / RQ_GT;
     static const long want = [] { const char* e = getenv("FR_SEARCH_BLOCKS"); return e && atol(e) > 0 ? atol(e) : 256L; }();   // tuning
@@ -469,21 +491,23 @@ extern "C" int fr_topk_workspace_bytes(int64_t Q, int64_t G, int k, size_t* out_
     return FR_OK;
 }
 
-extern "C" int fr_topk_search(const uint16_t* q, const uint16_t* g, int64_t Q, int64_t G, int d, int k,
-                              int64_t idx_offset, float* out_scores, int64_t* out_idx,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+static int search_check_args(const uint16_t* q, const uint16_t* g, int64_t Q, int64_t G, int d, int k,
+                             const float* out_scores, const int64_t* out_idx) {
     if (!q || !g || !out_scores || !out_idx || Q <= 0 || G <= 0) FR_FAIL(FR_ERR_ARG, "fr_topk_search: bad arguments");
     if (d != SEARCH_D) FR_FAIL(FR_ERR_UNSUPPORTED, "fr_topk_search: d must be 512");
     if (k < 1 || k > SEARCH_KMAX) FR_FAIL(FR_ERR_UNSUPPORTED, "fr_topk_search: k must be in 1..8");
     if (G > 0x7FFFFF00L) FR_FAIL(FR_ERR_UNSUPPORTED, "fr_topk_search: at most 2^31 gallery rows per call (shard it)");
-    size_t need = 0;
-    fr_topk_workspace_bytes(Q, G, k, &need);
-    if (!workspace || workspace_bytes < need) FR_FAIL(FR_ERR_WORKSPACE, "fr_topk_search: workspace too small");
+    return FR_OK;
+}
+
+// One search with the partial top-k lists in `workspace` (already checked to hold fr_topk_workspace_bytes(Q,G,k)).
+static int search_run(const uint16_t* q, const uint16_t* g, int64_t Q, int64_t G, int k,
+                      int64_t idx_offset, float* out_scores, int64_t* out_idx, void* workspace, void* stream) {
     if (Q > SEARCH_QCHUNK) {                  // chunks run back to back on the stream and share the workspace
         for (int64_t c0 = 0; c0 < Q; c0 += SEARCH_QCHUNK) {
             const int64_t qc = std::min<int64_t>(SEARCH_QCHUNK, Q - c0);
-            const int rc = fr_topk_search(q + c0 * SEARCH_D, g, qc, G, d, k, idx_offset, out_scores + c0 * k, out_idx + c0 * k,
-                                          workspace, workspace_bytes, stream);
+            const int rc = search_run(q + c0 * SEARCH_D, g, qc, G, k, idx_offset, out_scores + c0 * k, out_idx + c0 * k,
+                                      workspace, stream);
             if (rc) return rc;
         }
         return FR_OK;
@@ -503,48 +527,59 @@ extern "C" int fr_topk_search(const uint16_t* q, const uint16_t* g, int64_t Q, i
     if (rq) {
         const size_t lds = 2 * RQ_TILE_BYTES;
         dim3 grid((unsigned)(a.Qpad / RQ_QB), (unsigned)a.nsplit);
-        static bool rq_attr_set = false;
-        if (!rq_attr_set) {
-            FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_rq_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_rq_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_rq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            rq_attr_set = true;
-        }
+        { const int rc = search_set_lds_limits(); if (rc) return rc; }
         if (k == 1) hipLaunchKernelGGL((search_rq_kernel<1>), grid, dim3(512), lds, st, a);
         else if (k <= 5) hipLaunchKernelGGL((search_rq_kernel<5>), grid, dim3(512), lds, st, a);
         else hipLaunchKernelGGL((search_rq_kernel<8>), grid, dim3(512), lds, st, a);
         FR_LAUNCH_CHECK("search_rq_kernel");
         hipLaunchKernelGGL((topk_select_kernel<int>), dim3((unsigned)((Q + 127) / 128)), dim3(128), 0, st,
-                           a.part_s, a.part_i, a.nsplit * lists, a.Qpad * (long)k, (long)Q, k, (long)idx_offset,
+                           a.part_s, a.part_i, a.nsplit * lists, a.Qpad * (long)k, a.Qpad * (long)k, (long)Q, k, (long)idx_offset,
                            out_scores, out_idx);
         FR_LAUNCH_CHECK("topk_select_kernel");
         return FR_OK;
     }
     const size_t lds = 2 * S_BUF + S_PAD;
     dim3 grid((unsigned)(a.Qpad / 128), (unsigned)a.nsplit);
-    static bool attr_set = false;
-    if (!attr_set) {
-        FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    { const int rc = search_set_lds_limits(); if (rc) return rc; }
     if (k == 1) hipLaunchKernelGGL((search_kernel<1>), grid, dim3(256), lds, st, a);
     else if (k <= 5) hipLaunchKernelGGL((search_kernel<5>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((search_kernel<8>), grid, dim3(256), lds, st, a);
     FR_LAUNCH_CHECK("search_kernel");
     hipLaunchKernelGGL((topk_select_kernel<int>), dim3((unsigned)((Q + 127) / 128)), dim3(128), 0, st,
-                       a.part_s, a.part_i, a.nsplit * SEARCH_LISTS, a.Qpad * (long)k, (long)Q, k, (long)idx_offset,
+                       a.part_s, a.part_i, a.nsplit * SEARCH_LISTS, a.Qpad * (long)k, a.Qpad * (long)k, (long)Q, k, (long)idx_offset,
                        out_scores, out_idx);
     FR_LAUNCH_CHECK("topk_select_kernel");
     return FR_OK;
+}
+
+extern "C" int fr_topk_search(const uint16_t* q, const uint16_t* g, int64_t Q, int64_t G, int d, int k,
+                              int64_t idx_offset, float* out_scores, int64_t* out_idx,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    { const int rc = search_check_args(q, g, Q, G, d, k, out_scores, out_idx); if (rc) return rc; }
+    size_t need = 0;
+    fr_topk_workspace_bytes(Q, G, k, &need);
+    if (!workspace || workspace_bytes < need) FR_FAIL(FR_ERR_WORKSPACE, "fr_topk_search: workspace too small");
+    return search_run(q, g, Q, G, k, idx_offset, out_scores, out_idx, workspace, stream);
 }
 
 extern "C" int fr_topk_merge(const float* scores, const int64_t* idx, int P, int64_t Q, int k,
                              float* out_scores, int64_t* out_idx, void* stream) {
     if (!scores || !idx || P < 1 || Q <= 0 || k < 1 || k > SEARCH_KMAX) FR_FAIL(FR_ERR_ARG, "fr_topk_merge: bad arguments");
     hipLaunchKernelGGL((topk_select_kernel<int64_t>), dim3((unsigned)((Q + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
-                       scores, idx, P, (long)Q * k, (long)Q, k, 0L, out_scores, out_idx);
+                       scores, idx, P, (long)Q * k, (long)Q * k, (long)Q, k, 0L, out_scores, out_idx);
+    FR_LAUNCH_CHECK("topk_select_kernel");
+    return FR_OK;
+}
+
+extern "C" int fr_topk_merge_packed(const void* packed, int P, int64_t Q, int k,
+                                    float* out_scores, int64_t* out_idx, void* stream) {
+    if (!packed || !out_scores || !out_idx || P < 1 || Q <= 0 || k < 1 || k > SEARCH_KMAX) FR_FAIL(FR_ERR_ARG, "fr_topk_merge_packed: bad arguments");
+    if ((size_t)packed % 8) FR_FAIL(FR_ERR_ARG, "fr_topk_merge_packed: the receive buffer must be 8-byte aligned");
+    const size_t s_bytes = ((size_t)Q * k * 4 + 7) / 8 * 8, total = s_bytes + (size_t)Q * k * 8;     // one rank's message
+    const unsigned char* base = static_cast<const unsigned char*>(packed);
+    hipLaunchKernelGGL((topk_select_kernel<int64_t>), dim3((unsigned)((Q + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float*>(base), reinterpret_cast<const int64_t*>(base + s_bytes), P,
+                       (long)(total / 4), (long)(total / 8), (long)Q, k, 0L, out_scores, out_idx);
     FR_LAUNCH_CHECK("topk_select_kernel");
     return FR_OK;
 }

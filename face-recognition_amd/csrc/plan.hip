@@ -478,7 +478,7 @@ extern "C" int fr_plan_num_launches(const fr_plan* plan) { return plan ? plan->l
 // x_u8: `xv` is uint8 NHWC [batch,in_h,in_w,3] (fr_embed_u8) instead of fp32 NCHW.
 static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch, float* out,
                       void* workspace, size_t workspace_bytes, void* stream,
-                      int tap_layer, float* tap_out, hipEvent_t* events) {
+                      int tap_layer, float* tap_out, hipEvent_t* events, int inject_fail_layer = -1) {
     if (!plan || !xv || !out || batch <= 0) FR_FAIL(FR_ERR_ARG, "fr_embed: bad arguments");
     if (x_u8 && (plan->in_c != 3 || plan->input_slot >= 0 || plan->layers.empty() || plan->layers[0].kind != K_STEM))
         FR_FAIL(FR_ERR_UNSUPPORTED, "fr_embed_u8: the plan's first layer is not a 3-channel 3x3 stem");
@@ -507,6 +507,7 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
     for (int i = 0; i < nl; ++i) {
         const Layer& L = plan->layers[i];
         const bool last = (i == nl - 1);
+        if (i == inject_fail_layer) FR_FAIL(FR_ERR_HIP, "fr_embed: injected failure (FR_FAULT_INJECT_LAYER)");
         if (L.fused_next) {
             if (i == tap_layer) FR_FAIL(FR_ERR_ARG, "fr_embed_tap: this layer is fused into the next one (create the plan with FR_PLAN_NO_FUSE)");
             if (events) FR_HIP_CHECK(hipEventRecord(events[i + 1], st));
@@ -714,17 +715,37 @@ static int embed_split(const fr_plan* plan, const void* xv, bool x_u8, int batch
             const size_t in_el = (size_t)plan->in_c * plan->in_h * plan->in_w * (x_u8 ? 1 : sizeof(float));   // bytes per image
             const size_t out_el = (size_t)last.C * last.H * last.W;
             FR_HIP_CHECK(hipEventRecord(plan->ev_fork, st));
+            // Every exit path joins what it forked: a part that fails half way has already put kernels on its
+            // auxiliary stream that write the caller's workspace and output, so `st` must wait for them before the
+            // caller (who sees the error) frees or reuses those buffers.  The first error is the one reported.
             int rc = FR_OK;
+            std::string first_error;
+            auto note = [&](int r) { if (r && !rc) { rc = r; first_error = g_last_error; } };
+            auto hip_rc = [&](hipError_t e, const char* what) {
+                if (e == hipSuccess) return (int)FR_OK;
+                fr_set_error(std::string(what) + ": " + hipGetErrorString(e));
+                return (int)FR_ERR_HIP;
+            };
+            // test hook (tests/test_gpu_parity.py::test_split_failure_joins_auxiliary_streams): part 1 stops with an
+            // error after this many layers have been enqueued on its auxiliary stream
+            const char* inj = getenv("FR_FAULT_INJECT_LAYER");
             for (int i = 0; i < parts && !rc; ++i) {
                 hipStream_t si = i == 0 ? st : plan->aux[i - 1];
-                if (i > 0) FR_HIP_CHECK(hipStreamWaitEvent(si, plan->ev_fork, 0));
-                rc = embed_impl(plan, x + (size_t)n0[i] * in_el, x_u8, n0[i + 1] - n0[i], out + (size_t)n0[i] * out_el,
-                                reinterpret_cast<unsigned char*>(workspace) + off[i], off[i + 1] - off[i], si, -1, nullptr, nullptr);
                 if (i > 0) {
-                    FR_HIP_CHECK(hipEventRecord(plan->ev_join[i - 1], si));
-                    FR_HIP_CHECK(hipStreamWaitEvent(st, plan->ev_join[i - 1], 0));
+                    note(hip_rc(hipStreamWaitEvent(si, plan->ev_fork, 0), "hipStreamWaitEvent(fork)"));
+                    if (rc) break;                       // nothing was put on this auxiliary stream
+                }
+                note(embed_impl(plan, x + (size_t)n0[i] * in_el, x_u8, n0[i + 1] - n0[i], out + (size_t)n0[i] * out_el,
+                                reinterpret_cast<unsigned char*>(workspace) + off[i], off[i + 1] - off[i], si, -1, nullptr, nullptr,
+                                (inj && i == 1) ? atoi(inj) : -1));
+                if (i > 0) {
+                    const int j = hip_rc(hipEventRecord(plan->ev_join[i - 1], si), "hipEventRecord(join)");
+                    note(j);
+                    if (j == FR_OK) note(hip_rc(hipStreamWaitEvent(st, plan->ev_join[i - 1], 0), "hipStreamWaitEvent(join)"));
+                    else (void)hipStreamSynchronize(si);  // could not record the join: wait on the host rather than leave it running
                 }
             }
+            if (rc) fr_set_error(first_error);
             return rc;
         }
     }

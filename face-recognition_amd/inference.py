@@ -97,9 +97,25 @@ def embed_images(model, device, images: Sequence[np.ndarray], batch_size: int = 
     return torch.cat(outs) if outs else torch.empty(0, 512, device=device)
 
 
-def extract_batch_embeddings(model, device, image_folder: str, output_file: str = "assets/embeddings.json") -> dict:
-    """inference.py:125-164: folder -> {filename: [floats]}, saved as JSON (indent 2).  Per-file
-    errors are printed and skipped, as in the reference (:155-156)."""
+def _load_face_u8(img_path: str) -> np.ndarray:
+    """Image.open(...).convert("RGB") + the Resize step of get_transform (inference.py:102, :115-118) -> uint8
+    [112,112,3]; ToTensor and Normalize happen inside the stem kernel (fr_embed_u8)."""
+    from PIL import Image
+    try:
+        img = Image.open(img_path).convert("RGB")
+    except Exception as e:
+        raise FileNotFoundError(f"Error opening image {img_path}: {e}")
+    if img.size != (112, 112):
+        img = img.resize((112, 112), Image.BILINEAR)
+    return np.asarray(img, dtype=np.uint8)
+
+
+def extract_batch_embeddings(model, device, image_folder: str, output_file: str = "assets/embeddings.json",
+                             batch_size: int = 1024) -> dict:
+    """inference.py:125-164: folder -> {filename: [floats]}, saved as JSON (indent 2), same file order, same
+    messages; a file that cannot be read is reported and skipped (:155-156).  Unlike the reference's batch-1 loop
+    the readable images are embedded in GPU batches (embed_images) -- the per-image
+    arithmetic is that of extract_features, bit for bit."""
     image_extensions = (".jpg", ".jpeg", ".png", ".bmp", ".tiff")
     image_files = []
     for ext in image_extensions:
@@ -107,13 +123,20 @@ def extract_batch_embeddings(model, device, image_folder: str, output_file: str 
         image_files.extend(Path(image_folder).glob(f"*{ext.upper()}"))
     embeddings_dict = {}
     print(f"Extracting embeddings from {len(image_files)} images...")
-    for img_path in image_files:
-        try:
-            embedding = extract_features(model, device, str(img_path))
-            embeddings_dict[img_path.name] = embedding.tolist()
-            print(f"✓ Processed: {img_path.name}")
-        except Exception as e:
-            print(f"✗ Error processing {img_path.name}: {e}")
+    for lo in range(0, len(image_files), batch_size):
+        names, faces = [], []
+        for img_path in image_files[lo:lo + batch_size]:
+            try:
+                faces.append(_load_face_u8(str(img_path)))
+                names.append(img_path.name)
+            except Exception as e:
+                print(f"✗ Error processing {img_path.name}: {e}")
+        if not faces:
+            continue
+        emb = embed_images(model, device, faces, batch_size).cpu().numpy()
+        for name, e in zip(names, emb):
+            embeddings_dict[name] = e.tolist()
+            print(f"✓ Processed: {name}")
     os.makedirs(os.path.dirname(output_file), exist_ok=True)
     with open(output_file, "w") as f:
         json.dump(embeddings_dict, f, indent=2)
@@ -135,19 +158,21 @@ def cosine_pairs(a: torch.Tensor, b: torch.Tensor, eps: float = 0.0, threshold: 
 
 
 def compute_similarity(feat1: np.ndarray, feat2: np.ndarray) -> np.float32:
-    """utils/face_utils.py:74-87 semantics (cosine, no epsilon, np.float32 result), computed by
-    fr_cosine_pairs on the GPU."""
-    dev = torch.device("cuda", torch.cuda.current_device())
-    a = torch.from_numpy(np.ascontiguousarray(feat1, dtype=np.float32).ravel()[None]).to(dev)
-    b = torch.from_numpy(np.ascontiguousarray(feat2, dtype=np.float32).ravel()[None]).to(dev)
-    sim, _ = cosine_pairs(a, b, eps=0.0)
-    return np.float32(sim.cpu().numpy()[0])
+    """utils/face_utils.py:74-87: host NumPy arrays in, np.float32 out -- the reference's own three NumPy lines
+    (ravel, dot / (norm * norm), no epsilon).  Host glue by contract, as in the reference; the device form for
+    embeddings that are already on the GPU is ``cosine_pairs`` (fr_cosine_pairs), which compare_faces and eval use."""
+    feat1 = np.asarray(feat1).ravel()
+    feat2 = np.asarray(feat2).ravel()
+    return np.dot(feat1, feat2) / (np.linalg.norm(feat1) * np.linalg.norm(feat2))
 
 
 def compare_faces(model, device, img1_path: str, img2_path: str, threshold: float = 0.35) -> tuple:
-    """inference.py:167-177."""
-    feat1 = extract_features(model, device, img1_path)
-    feat2 = extract_features(model, device, img2_path)
-    similarity = compute_similarity(feat1, feat2)
+    """inference.py:167-177: (similarity np.float32, is_same np.bool_).  Both faces go through the backbone as ONE
+    batch of two and are scored on the device (fr_cosine_pairs, eps = 0 as utils/face_utils.py:86): one H2D copy,
+    one D2H copy of the score, instead of two forwards, two D2H copies and a host dot product."""
+    faces = [_load_face_u8(img1_path), _load_face_u8(img2_path)]
+    emb = embed_images(model, device, faces)
+    sim, _ = cosine_pairs(emb[0:1], emb[1:2], eps=0.0, threshold=threshold)
+    similarity = np.float32(sim.cpu().numpy()[0])
     is_same = similarity > threshold
     return similarity, is_same

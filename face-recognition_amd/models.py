@@ -26,8 +26,22 @@ _ACT = {None: _lib.FR_ACT_NONE, "prelu": _lib.FR_ACT_PRELU, "hswish": _lib.FR_AC
 
 
 def default_precision() -> str:
-    """Plan precision used when a model does not set one: env FR_PRECISION or "bf16"."""
-    return os.environ.get("FR_PRECISION", "bf16")
+    """Plan precision used when a model does not set one: env FR_PRECISION or "auto".
+
+    "auto" picks, per backbone family, the cheapest mode that meets the parity bar (embedding cosine >= 0.9999
+    against the reference, BASELINE.json north_star) on raw-init AND on BN-calibrated ("trained-like") weights,
+    as measured on the goldens of tests/golden (tools/precision_probe.py, MI355X):
+
+        family       bf16 raw-init         bf16 BN-calibrated      f32 (split-bf16, 3 MFMA passes)
+        MobileNetV1  0.99986  (fails)      0.9961  (fails)         1.0000000 / 1.0000000
+        MobileNetV2  0.99990  (fails)      0.9973  (fails)         1.0000000 / 1.0000000
+        V3 small     0.99995               0.974   (fails)         1.0000000 / 0.9999993
+        V3 large     0.99995               0.946   (fails)         1.0000000 / 0.9999993
+        SphereFace   0.99997 (no BatchNorm: no calibrated variant) 1.0000000
+
+    so MobileNets default to "f32" and SphereFace to "bf16".  "bf16" stays available as an explicit choice (it is
+    the mode BASELINE.json configs[1] names, and it meets the bar on that config's random-init weights)."""
+    return os.environ.get("FR_PRECISION", "auto")
 
 
 def default_fuse() -> bool:
@@ -149,7 +163,8 @@ class GDC(nn.Module):
 class HipBackbone(nn.Module):
     """float32[N,3,112,112] (NCHW, cuda) -> float32[N,embedding_dim], computed by libfr_hip.so."""
 
-    precision: Optional[str] = None      # "bf16" | "f32"; None -> default_precision()
+    precision: Optional[str] = None      # "bf16" | "f32" | "auto"; None -> default_precision()
+    auto_precision: str = "f32"          # what "auto" resolves to for this family (see default_precision)
 
     def __init__(self) -> None:
         super().__init__()
@@ -180,6 +195,8 @@ class HipBackbone(nn.Module):
 
     def plan(self, device: torch.device, precision: Optional[str] = None, fuse: Optional[bool] = None) -> "_Plan":
         prec = precision or self.precision or default_precision()
+        if prec == "auto":
+            prec = self.auto_precision
         fuse = default_fuse() if fuse is None else fuse
         if prec not in _lib.PRECISIONS:
             raise ValueError(f"unknown precision '{prec}' (expected one of {list(_lib.PRECISIONS)})")
@@ -230,6 +247,7 @@ class _Plan:
             _lib.check(self.lib.fr_plan_create(arr, self.n_layers, 3, 112, 112, _lib.PRECISIONS[precision] | (0 if fuse else _lib.FR_PLAN_NO_FUSE),
                                                C.byref(handle)), "fr_plan_create")
         self.handle = handle
+        self.precision = precision
         self._ws: Optional[torch.Tensor] = None
         c, h, w = C.c_int(), C.c_int(), C.c_int()
         self.dims = []
@@ -486,6 +504,8 @@ class _SphereResidual(nn.Module):
 
 class SphereNet(HipBackbone):
     """models/sphereface.py:51-129."""
+
+    auto_precision = "bf16"              # no BatchNorm, K >= 576 dense convs: bf16 measures cos >= 0.99997
 
     def __init__(self, layers: Sequence[int], embedding_dim: int = 512, in_channels: int = 3) -> None:
         super().__init__()

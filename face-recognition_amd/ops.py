@@ -35,7 +35,10 @@ _defs.define("topk_merge(Tensor scores, Tensor idx, int k) -> (Tensor, Tensor)")
 _impl = torch.library.Library(_NS, "IMPL", "CUDA")
 _meta = torch.library.Library(_NS, "IMPL", "Meta")
 
-_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}     # (plan handle | 0 for search, device index) -> scratch
+# (plan handle | 0 for search, device index, stream handle) -> scratch.  Keyed by STREAM as well: two calls enqueued
+# on different streams can overlap on the GPU, and a workspace shared between them (the same model on two streams,
+# two Matchers) would be written by both at once.  Calls on one stream are ordered, so they share.
+_workspaces: Dict[Tuple[int, int, int], torch.Tensor] = {}
 
 
 def _stream(dev) -> int:
@@ -43,7 +46,7 @@ def _stream(dev) -> int:
 
 
 def _workspace(key: int, dev: torch.device, nbytes: int) -> torch.Tensor:
-    k = (key, dev.index)
+    k = (key, dev.index, _stream(dev))
     ws = _workspaces.get(k)
     if ws is None or ws.numel() < nbytes:
         _workspaces.pop(k, None)

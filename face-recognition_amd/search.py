@@ -83,6 +83,25 @@ class Matcher:
             raise ValueError("queries must be bf16 [Q,512] on the gallery's device")
         return torch.ops.fr_hip.topk_search(q.contiguous(), self.g, self.k, self.idx_offset)   # ops.py -> fr_topk_search
 
+    def search_into(self, q: torch.Tensor, scores: torch.Tensor, idx: torch.Tensor) -> None:
+        """fr_topk_search with caller-provided outputs (fp32 [Q,k] / int64 [Q,k] contiguous views, e.g. of a packed
+        exchange message): nothing is allocated per call beyond the cached workspace."""
+        Q, G = q.shape[0], self.g.shape[0]
+        if Q == 0:
+            return
+        if G == 0:
+            scores.fill_(float("-inf")); idx.fill_(-1)
+            return
+        assert scores.is_contiguous() and idx.is_contiguous() and scores.shape == (Q, self.k) == idx.shape
+        from . import ops
+        lib = _lib.lib()
+        need = C.c_size_t()
+        _lib.check(lib.fr_topk_workspace_bytes(Q, G, self.k, C.byref(need)), "fr_topk_workspace_bytes")
+        ws = ops._workspace(0, q.device, need.value)
+        with torch.cuda.device(q.device):
+            _lib.check(lib.fr_topk_search(q.data_ptr(), self.g.data_ptr(), Q, G, DIM, self.k, self.idx_offset, scores.data_ptr(),
+                                          idx.data_ptr(), ws.data_ptr(), ws.numel(), _stream(q.device)), "fr_topk_search")
+
 
 def merge_topk(scores: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """[P,Q,k] per-shard results -> global [Q,k] (fr_topk_merge on the GPU)."""
@@ -97,9 +116,9 @@ def merge_topk(scores: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.T
 
 
 def all_gather_topk(scores: torch.Tensor, idx: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """The one exchange step of the sharded search: all_gather of [Q,k] scores and indices ->
-    [P,Q,k].  With backend "nccl" this is ncclAllGather (RCCL) over xGMI; message size per rank is
-    Q*k*(4+8) bytes (3.9 MB at Q = 64k, k = 5)."""
+    """Unpipelined form of the exchange: all_gather of [Q,k] scores and indices -> [P,Q,k] (two collectives).
+    ShardedMatcher uses ``exchange_topk_chunks`` below; this one is kept for callers that already hold separate
+    score / index tensors."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     Q, k = scores.shape
@@ -110,21 +129,81 @@ def all_gather_topk(scores: torch.Tensor, idx: torch.Tensor, group=None) -> Tupl
     return gs.view(world, Q, k), gi.view(world, Q, k)
 
 
+# ---- the exchange step, pipelined over query chunks ---------------------------------------------
+# One packed message per rank and chunk: [Q*k fp32 scores, padded to 8 B | Q*k int64 global indices] -- 3.9 MB at
+# Q = 64 k, k = 5.  The local search writes straight into the message, ONE all_gather moves it (backend "nccl" =
+# ncclAllGather of RCCL over xGMI), and the merge reads the receive buffer as it is (fr_topk_merge_packed).
+
+def packed_bytes(Q: int, k: int) -> Tuple[int, int]:
+    """(offset of the index block, total bytes) of one rank's message for Q queries."""
+    s_bytes = (Q * k * 4 + 7) // 8 * 8
+    return s_bytes, s_bytes + Q * k * 8
+
+
+def packed_views(buf: torch.Tensor, Q: int, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The fp32 [Q,k] score block and the int64 [Q,k] index block of a message (views, no copy)."""
+    off, total = packed_bytes(Q, k)
+    assert buf.dtype == torch.uint8 and buf.numel() == total
+    return buf[:Q * k * 4].view(torch.float32).view(Q, k), buf[off:].view(torch.int64).view(Q, k)
+
+
+def exchange_topk_chunks(q: torch.Tensor, k: int, chunk: int, world: int, group, local_search, merge):
+    """Sharded search of ``q`` in chunks of ``chunk`` queries with the exchange of chunk t overlapped with the
+    local search of chunk t+1:
+
+        local_search(q_chunk, scores_view, idx_view)   fills this rank's message with its shard's top-k (global indices)
+        all_gather_into_tensor(..., async_op=True)     runs on the communicator's own stream (RCCL) / thread (gloo)
+        merge(recv [P, bytes], Qc, out_scores, out_idx) deterministic P*k -> k merge, once the gather has landed
+
+    Device-agnostic on purpose (the CPU test drives it over gloo with stand-in local_search / merge); on the GPU
+    ``Work.wait()`` only makes the compute stream wait -- the host never blocks."""
+    import torch.distributed as dist
+    Q = q.shape[0]
+    out_s = torch.empty((Q, k), dtype=torch.float32, device=q.device)
+    out_i = torch.empty((Q, k), dtype=torch.int64, device=q.device)
+    pending = None                                        # (work, recv, lo, hi) of the chunk in flight
+    def finish(p):
+        work, recv, lo, hi = p
+        work.wait()
+        merge(recv, hi - lo, out_s[lo:hi], out_i[lo:hi])
+    for lo in range(0, Q, chunk):
+        hi = min(Q, lo + chunk)
+        _, total = packed_bytes(hi - lo, k)
+        msg = torch.empty(total, dtype=torch.uint8, device=q.device)
+        sv, iv = packed_views(msg, hi - lo, k)
+        local_search(q[lo:hi], sv, iv)
+        recv = torch.empty((world, total), dtype=torch.uint8, device=q.device)
+        work = dist.all_gather_into_tensor(recv.view(-1), msg, group=group, async_op=True)
+        if pending is not None:
+            finish(pending)                               # chunk t-1 merges while chunk t's gather is on the wire
+        pending = (work, recv, lo, hi)
+    if pending is not None:
+        finish(pending)
+    return out_s, out_i
+
+
 class ShardedMatcher:
     """One process per GPU; this rank holds gallery rows shard_range(G, rank, world)."""
 
     def __init__(self, local_gallery: torch.Tensor, n_gallery_total: int, rank: int, world: int, k: int = 5,
-                 group=None) -> None:
+                 group=None, chunk: int = 32768) -> None:
         lo, hi = shard_range(n_gallery_total, rank, world)
         if local_gallery.shape[0] != hi - lo:
             raise ValueError(f"rank {rank} must hold rows [{lo},{hi}) of the gallery")
         self.local = Matcher(local_gallery, idx_offset=lo, k=k)
         self.k, self.world, self.group = k, world, group
+        self.chunk = int(chunk)                            # queries per launch of the search kernel = per message
+
+    def _merge(self, recv: torch.Tensor, Qc: int, out_s: torch.Tensor, out_i: torch.Tensor) -> None:
+        with torch.cuda.device(recv.device):
+            _lib.check(_lib.lib().fr_topk_merge_packed(recv.data_ptr(), recv.shape[0], Qc, self.k, out_s.data_ptr(),
+                                                       out_i.data_ptr(), _stream(recv.device)), "fr_topk_merge_packed")
 
     def search(self, q: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        s, i = self.local.search(q)
         import torch.distributed as dist
         if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
-            return s, i
-        gs, gi = all_gather_topk(s, i, self.group)
-        return merge_topk(gs, gi, self.k)
+            return self.local.search(q)
+        if q.dtype != torch.bfloat16 or q.dim() != 2 or q.shape[1] != DIM or q.device != self.local.g.device:
+            raise ValueError("queries must be bf16 [Q,512] on the gallery's device")
+        return exchange_topk_chunks(q.contiguous(), self.k, self.chunk, self.world, self.group,
+                                    self.local.search_into, self._merge)

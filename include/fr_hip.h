@@ -99,7 +99,9 @@ int fr_plan_num_launches(const fr_plan* plan);
  * reference backbones return (utils/layers.py:188-191).
  * Asynchronous on `stream`.  A batch of 128 images or more is cut into two sub-batches, the second of
  * which runs on an auxiliary stream owned by the plan (forked from and joined back to `stream` with
- * events), so one plan serves one host thread at a time; results do not depend on the split. */
+ * events), so one plan serves one host thread at a time; results do not depend on the split.  A workspace must not
+ * be shared by calls that can overlap on the GPU: calls enqueued on different streams need different workspaces
+ * (the host layer keeps one per plan, device and stream). */
 int fr_embed(const fr_plan* plan, const float* x, int batch, float* out,
              void* workspace, size_t workspace_bytes, void* stream);
 /* Replaces: `get_transform()(img)` + `model(tensor)` (inference.py:98-106 and :120-122) for images that
@@ -167,6 +169,13 @@ int fr_topk_search(const uint16_t* q, const uint16_t* g, int64_t Q, int64_t G, i
  * global top-k [Q,k]; deterministic: descending score, ties to the lower global index. */
 int fr_topk_merge(const float* scores, const int64_t* idx, int P, int64_t Q, int k,
                   float* out_scores, int64_t* out_idx, void* stream);
+
+/* Same merge, reading the receive buffer of ONE all-gather as it is (no reference counterpart):
+ * packed = P messages back to back, each [Q*k fp32 scores, padded to a multiple of 8 bytes | Q*k int64 global
+ * indices] -- the layout fr_topk_search fills when out_scores / out_idx point into such a message
+ * (face-recognition_amd/search.py: packed_bytes, exchange_topk_chunks). */
+int fr_topk_merge_packed(const void* packed, int P, int64_t Q, int k,
+                         float* out_scores, int64_t* out_idx, void* stream);
 
 #ifdef __cplusplus
 }

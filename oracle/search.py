@@ -104,3 +104,22 @@ def merge_topk(scores: np.ndarray, idx: np.ndarray, k: int = 5) -> Tuple[np.ndar
     i = idx.transpose(1, 0, 2).reshape(Q, P * kk)
     order = np.lexsort((i, -s), axis=1)[:, :k]
     return np.take_along_axis(s, order, axis=1), np.take_along_axis(i, order, axis=1)
+
+
+def topk_cosine_fp32_chunked(q, g, k: int = 5, chunk: int = 65536):
+    """The CPU baseline of the matcher: fp32 ``Q @ G_chunk.T`` + ``torch.topk(k)`` per gallery
+    chunk with a running merge, all host cores (PyTorch CPU / oneDNN).  q [Q,d], g [G,d] torch fp32, rows already
+    L2-normalised.  Same definition as topk_cosine (which is float64 NumPy with an explicit tie order and is the
+    checker); this one is the form a CPU user of the reference would write for speed.  Returns (scores, indices)."""
+    import torch
+    Q = q.shape[0]
+    best_s = torch.full((Q, k), float("-inf"))
+    best_i = torch.full((Q, k), -1, dtype=torch.int64)
+    for lo in range(0, g.shape[0], chunk):
+        s = q @ g[lo:lo + chunk].T
+        cs, ci = torch.topk(s, min(k, s.shape[1]), dim=1)
+        ms = torch.cat([best_s, cs], dim=1)
+        mi = torch.cat([best_i, ci + lo], dim=1)
+        best_s, sel = torch.topk(ms, k, dim=1)
+        best_i = torch.gather(mi, 1, sel)
+    return best_s, best_i

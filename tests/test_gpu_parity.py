@@ -145,6 +145,62 @@ def test_bn_calibrated_weights_f32(name, golden_dir, golden_x):
     assert np.abs(y - g["emb"]).max() <= 2e-3 * np.abs(g["emb"]).max()
 
 
+def _calibrated_state(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"bncal_{name}.npz"))
+    sd = ob.seeded(name, 0).state_dict()
+    for i, k in enumerate(g["keys"]):
+        sd[str(k)] = torch.from_numpy(g[f"s{i}"])
+    return sd, g["emb"]
+
+
+@pytest.mark.parametrize("calibrated", [False, True])
+@pytest.mark.parametrize("name", ob.MODEL_NAMES)
+def test_default_precision_meets_the_bar_on_every_backbone(name, calibrated, golden_dir, golden_x):
+    """What load_model(...) -> model(x) runs when nobody chooses a precision ("auto", models.default_precision):
+    every backbone x {raw init, BN-calibrated 'trained-like' statistics} against the reference's golden embeddings
+    at the north_star bar, cosine >= 0.9999.  (SphereFace has no BatchNorm, hence no calibrated variant.)"""
+    if calibrated and name.startswith("sphere"):
+        pytest.skip("SphereFace has no BatchNorm: there is no calibrated variant")
+    if calibrated:
+        sd, want = _calibrated_state(name, golden_dir)
+    else:
+        sd, want = None, np.load(os.path.join(golden_dir, f"emb_{name}.npz"))["emb"]
+    m = product(name, sd)
+    assert m.precision is None and fr.default_precision() == "auto"
+    with torch.no_grad():
+        y = m(golden_x.to(DEV)).cpu().numpy()
+    c = cos_rows(y, want)
+    assert c.min() >= COS_BAR, (m.plan(DEV).precision, c)
+    assert m.plan(DEV).precision == ("bf16" if name.startswith("sphere") else "f32")
+
+
+# measured on MI355X (tools/precision_probe.py): min cosine of the single-pass bf16 mode over the 8 golden inputs
+_BF16_MEASURED = {("mobilenetv1", False): 0.99986, ("mobilenetv2", False): 0.99990, ("mobilenetv3_small", False): 0.99995,
+                  ("mobilenetv3_large", False): 0.99995, ("mobilenetv1", True): 0.9961, ("mobilenetv2", True): 0.9973,
+                  ("mobilenetv3_small", True): 0.974, ("mobilenetv3_large", True): 0.946}
+
+
+@pytest.mark.parametrize("name,calibrated", sorted(_BF16_MEASURED))
+def test_bf16_mode_against_the_bar_is_what_the_policy_says(name, calibrated, golden_dir, golden_x):
+    """The explicit bf16 mode (the one BASELINE.json configs[1] names) against the same goldens.  It meets the bar on
+    raw-init MobileNetV3 (the benchmarked configuration) and misses it on MobileNetV1/V2 and on every BN-calibrated
+    MobileNet -- which is WHY "auto" resolves to f32 for the MobileNets.  The test pins both facts: where bf16 is
+    claimed to pass it must pass, and elsewhere 1 - cos must stay within 1.5x of what was measured, so that a
+    change in the bf16 kernels that shifts its accuracy is seen."""
+    if calibrated:
+        sd, want = _calibrated_state(name, golden_dir)
+    else:
+        sd, want = None, np.load(os.path.join(golden_dir, f"emb_{name}.npz"))["emb"]
+    with torch.no_grad():
+        y = product(name, sd)(golden_x.to(DEV), precision="bf16").cpu().numpy()
+    c = cos_rows(y, want).min()
+    if not calibrated and name.startswith("mobilenetv3"):
+        assert c >= COS_BAR, c
+    else:
+        assert c < COS_BAR, f"{name}: bf16 now meets the bar ({c}); revisit auto_precision"
+    assert 1 - c <= 1.5 * (1 - _BF16_MEASURED[(name, calibrated)]), c
+
+
 @pytest.mark.parametrize("name", ["mobilenetv3_large", "mobilenetv3_small", "mobilenetv2", "mobilenetv1"])
 def test_fused_depthwise_pointwise_equals_unfused(name, golden_x):
     """dwp_kernel (depthwise + following 1x1 conv, depthwise result kept in LDS) rounds and accumulates
@@ -378,8 +434,8 @@ def _lfw_fixture(tmp_path, n_ids=40, per_id=3, n_pairs=120, seed=3):
     return root, images, lines[1:]
 
 
-@pytest.mark.parametrize("calibrated", [False, True])
-def test_lfw_pair_verification_config1(tmp_path, golden_dir, calibrated):
+@pytest.mark.parametrize("calibrated,precision", [(False, None), (True, None), (False, "bf16")])
+def test_lfw_pair_verification_config1(tmp_path, golden_dir, calibrated, precision):
     """BASELINE config 1 (reduced pair count so the CPU oracle's batch-1 loop stays short):
     mobilenetv3_small, LFW-layout annotation, eval() triple vs the oracle's restated pair loop."""
     root, images, pair_lines = _lfw_fixture(tmp_path)
@@ -391,7 +447,8 @@ def test_lfw_pair_verification_config1(tmp_path, golden_dir, calibrated):
             sd[str(k)] = torch.from_numpy(g[f"s{i}"])
         onet.load_state_dict(sd)
     model = product("mobilenetv3_small", onet.state_dict())
-    model.precision = "f32"
+    model.precision = precision          # None: the product default ("auto" -> f32 for MobileNets), what load_model() -> eval() runs
+    assert model.plan(DEV).precision == (precision or "f32")
 
     def loader(path):
         if path not in images:
@@ -620,3 +677,182 @@ def test_alignment_warp_bit_exact_vs_oracle():
         fr.align.warp_faces([torch.from_numpy(imgs[0])], Ms[:1])
     emb = product("mobilenetv3_small").forward_u8(torch.from_numpy(got).to(DEV), precision="bf16")
     assert emb.shape == (6, 512) and torch.isfinite(emb).all()
+
+
+# ---- the reference's file-based entry points on the GPU (inference.py:109-177, evaluate.py:179-194) ------------------
+def _write_faces(tmp_path, n=5):
+    from PIL import Image
+    faces = osc.synthetic_faces(n, 1, seed=77).reshape(n, 112, 112, 3)
+    names = [f"face_{i}.png" for i in range(n)]
+    names[1] = "face_1.PNG"                                  # upper-case extension: globbed too (inference.py:141-144)
+    for nme, a in zip(names, faces):
+        Image.fromarray(a).save(str(tmp_path / nme), format="PNG")       # PNG: lossless, so the oracle sees the same pixels
+    return names, faces
+
+
+@pytest.mark.parametrize("name", ["mobilenetv3_small", "sphere20"])
+def test_file_entry_points_against_oracle(name, tmp_path, capsys):
+    """extract_features, extract_deep_features, compare_faces and extract_batch_embeddings called the way the
+    reference's __main__ and notebooks call them -- image FILES in, NumPy / JSON out, model from load_model() on
+    cuda with the default precision -- against the oracle forward and oracle/scoring.py on the same pixels:
+    embedding cosine >= 0.9999, similarity |delta| <= 1e-3, same decision, same JSON keys and values."""
+    import json
+    from PIL import Image
+    names, faces = _write_faces(tmp_path)
+    (tmp_path / "broken.jpg").write_bytes(b"not an image")
+    (tmp_path / "notes.txt").write_text("ignored")
+    onet = ob.seeded(name, 0)
+    ck = tmp_path / "w.pth"
+    torch.save(onet.state_dict(), ck)
+    model = fr.load_model(name, str(ck), DEV)
+    assert not model.training and next(model.parameters()).is_cuda
+    with torch.no_grad():
+        want = onet(torch.stack([osc.to_model_input(a) for a in faces])).numpy()
+
+    f0 = fr.extract_features(model, DEV, str(tmp_path / names[0]))
+    assert isinstance(f0, np.ndarray) and f0.shape == (512,) and f0.dtype == np.float32
+    assert cos_rows(f0[None], want[:1]).min() >= COS_BAR
+    t0 = fr.evaluate.extract_deep_features(model, Image.open(str(tmp_path / names[0])).convert("RGB"), DEV)
+    assert isinstance(t0, torch.Tensor) and not t0.is_cuda and t0.shape == (512,)
+    assert np.array_equal(t0.numpy(), f0)
+    with pytest.raises(FileNotFoundError):
+        fr.extract_features(model, DEV, str(tmp_path / "missing.png"))
+    with pytest.raises(FileNotFoundError):
+        fr.extract_features(model, DEV, str(tmp_path / "broken.jpg"))
+
+    for i, j in ((0, 1), (2, 3), (4, 4)):
+        sim, same = fr.compare_faces(model, DEV, str(tmp_path / names[i]), str(tmp_path / names[j]), threshold=0.35)
+        ref = osc.compute_similarity(want[i], want[j])
+        assert type(sim) is np.float32 and isinstance(same, (bool, np.bool_))
+        assert abs(float(sim) - float(ref)) <= 1e-3, (i, j, sim, ref)
+        if abs(float(ref) - 0.35) > 1e-3:
+            assert bool(same) == bool(ref > 0.35)
+    assert fr.compare_faces(model, DEV, str(tmp_path / names[4]), str(tmp_path / names[4]))[1]      # a face matches itself
+    sim_host = fr.compute_similarity(want[0], want[1])
+    assert type(sim_host) is np.float32 and sim_host == osc.compute_similarity(want[0], want[1])
+    with pytest.raises(FileNotFoundError):
+        fr.compare_faces(model, DEV, str(tmp_path / names[0]), str(tmp_path / "missing.png"))
+
+    out = tmp_path / "assets" / "embeddings.json"
+    d = fr.extract_batch_embeddings(model, DEV, str(tmp_path), str(out))
+    printed = capsys.readouterr().out
+    assert sorted(d) == sorted(names) and "broken.jpg" not in d
+    assert "✗ Error processing broken.jpg" in printed and printed.count("✓ Processed") == len(names)
+    assert f"Extracting embeddings from {len(names) + 1} images" in printed
+    back = json.load(open(out))
+    assert list(back) == list(d) and all(isinstance(v, list) and len(v) == 512 for v in back.values())
+    got = np.array([back[n] for n in names], dtype=np.float32)
+    assert cos_rows(got, want).min() >= COS_BAR
+    assert np.array_equal(got[0], f0)                        # batched u8 path == the per-image path, bit for bit
+    assert open(out).read().startswith("{\n  \"")            # indent=2, as json.dump(..., indent=2) in the reference
+    # batches smaller than the folder: same dict
+    d2 = fr.extract_batch_embeddings(model, DEV, str(tmp_path), str(tmp_path / "a2" / "e.json"), batch_size=2)
+    assert d2 == d
+
+
+def test_file_entry_points_resize_other_sizes(tmp_path):
+    """Images that are not 112x112 go through the Resize step (PIL bilinear, as torchvision does for PIL inputs;
+    parity unpinned: torchvision is not importable here).  Host logic only -- the oracle side uses the same PIL call."""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, size=(150, 130, 3), dtype=np.uint8)
+    Image.fromarray(a).save(str(tmp_path / "big.png"))
+    model = product("mobilenetv3_small")
+    f = fr.extract_features(model, DEV, str(tmp_path / "big.png"))
+    small = np.asarray(Image.fromarray(a).resize((112, 112), Image.BILINEAR), dtype=np.uint8)
+    with torch.no_grad():
+        want = ob.seeded("mobilenetv3_small", 0)(osc.to_model_input(small)[None]).numpy()
+    assert cos_rows(f[None], want).min() >= COS_BAR
+
+
+# ---- robustness (VERDICT round 1, item 8) ------------------------------------------------------------------------------
+def test_split_failure_joins_auxiliary_streams(golden_x, monkeypatch):
+    """fr_embed cuts a batch >= 128 into two parts on two streams.  When the second part fails half way (test hook
+    FR_FAULT_INJECT_LAYER: an error after that many layers were enqueued on the auxiliary stream), the call must
+    return the error AND leave the caller's stream waiting for what was already enqueued: afterwards the same
+    workspace is reused at once by a good call, whose result must be right."""
+    m = product("mobilenetv3_small")
+    x = golden_x.to(DEV).repeat(32, 1, 1, 1)                 # 256 images: 128 + 128
+    with torch.no_grad():
+        good = m(x, precision="bf16")
+        monkeypatch.setenv("FR_FAULT_INJECT_LAYER", "9")
+        with pytest.raises(RuntimeError, match="injected failure"):
+            m(x, precision="bf16")
+        monkeypatch.delenv("FR_FAULT_INJECT_LAYER")
+        again = m(x, precision="bf16")                       # same plan, same workspace, no synchronisation in between
+    torch.cuda.synchronize(DEV)
+    assert torch.equal(again, good)
+
+
+def test_two_streams_get_two_workspaces():
+    """Two searches and two forwards enqueued from one host thread on two torch streams may overlap on the GPU: the
+    host layer must not hand them one shared workspace (ops._workspace is keyed by stream)."""
+    from face_recognition_amd import ops
+    G = 400_000
+    g = fr.search.synth_rows(7, 0, G, DEV, plant_seed=11, n_plant=8, n_gallery_total=G)
+    qa = fr.search.synth_rows(11, 0, 3000, DEV)
+    qb = fr.search.synth_rows(13, 0, 3000, DEV)
+    ma, mb = fr.search.Matcher(g, k=5), fr.search.Matcher(g, k=5)
+    ra, rb = ma.search(qa), mb.search(qb)                    # reference results, one after the other
+    torch.cuda.synchronize(DEV)
+    s1, s2 = torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)
+    outs = []
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            oa = ma.search(qa)
+        with torch.cuda.stream(s2):
+            ob_ = mb.search(qb)
+        outs.append((oa, ob_))
+    torch.cuda.synchronize(DEV)
+    for oa, ob_ in outs:
+        assert torch.equal(oa[1], ra[1]) and torch.equal(oa[0], ra[0])
+        assert torch.equal(ob_[1], rb[1]) and torch.equal(ob_[0], rb[0])
+    keys = [k for k in ops._workspaces if k[0] == 0 and k[1] == DEV.index]
+    assert len({k[2] for k in keys}) >= 3                    # default stream + the two side streams
+
+
+def test_search_config4_at_full_size_by_properties():
+    """BASELINE.json configs[3] at its full size (10 M gallery rows x 65 536 queries, 512-d bf16, k = 5), far beyond
+    what the oracle scores: every one of the 1024 planted queries finds its planted row first, scores are sorted,
+    the five rows of a query are distinct and valid, a 4096-query slice searched alone gives the same rows (other
+    launch geometry), and a 4096-row window of the gallery agrees with the oracle."""
+    G, Q, npl = 10_000_000, 65_536, 1024
+    g = fr.search.synth_rows(7, 0, G, DEV, plant_seed=11, n_plant=npl, n_gallery_total=G)
+    q = fr.search.synth_rows(11, 0, Q, DEV)
+    s, i = fr.search.Matcher(g, k=5).search(q)
+    planted = torch.tensor([osr.plant_row(t, G, npl) for t in range(npl)], device=DEV)
+    assert torch.equal(i[:npl, 0], planted) and (s[:npl, 0] > 0.9).all()
+    assert (s[:, 1:] <= s[:, :-1]).all() and (i >= 0).all() and (i < G).all()
+    assert (i.sort(dim=1).values.diff(dim=1) > 0).all()
+    assert (s[npl:, 0] < 0.5).all()                          # unplanted queries: no accidental near-duplicate
+    s2, i2 = fr.search.Matcher(g, k=5).search(q[40_000:44_096])
+    assert torch.equal(i2, i[40_000:44_096]) and torch.equal(s2, s[40_000:44_096])
+    lo = 7_000_000
+    gf = osr.bf16_bits_to_f32(g[lo:lo + 4096].view(torch.int16).cpu().numpy().view(np.uint16))
+    qf = osr.bf16_bits_to_f32(q[:32].view(torch.int16).cpu().numpy().view(np.uint16))
+    os_, oi, _ = osr.topk_cosine(qf, gf, 5)
+    ss, si = fr.search.Matcher(g[lo:lo + 4096].contiguous(), idx_offset=lo, k=5).search(q[:32])
+    assert np.abs(ss.cpu().numpy() - os_).max() <= 1e-3 and np.array_equal(si[:, 0].cpu().numpy(), oi[:, 0] + lo)
+
+
+def test_packed_exchange_merge_equals_plain_merge():
+    """fr_topk_search writing straight into packed exchange messages + fr_topk_merge_packed on the concatenated
+    messages (what ShardedMatcher does around its one all_gather per chunk) against the plain search + merge:
+    3 fake shards on one device, odd Q*k (padding between the score and index blocks), bit for bit."""
+    G, Q, k = 30011, 77, 5
+    g = fr.search.synth_rows(7, 0, G, DEV, plant_seed=11, n_plant=8, n_gallery_total=G)
+    q = fr.search.synth_rows(11, 0, Q, DEV)
+    s1, i1 = fr.search.Matcher(g, k=k).search(q)
+    P = 3
+    off, total = fr.search.packed_bytes(Q, k)
+    assert off % 8 == 0 and off == 1544 and total == off + Q * k * 8
+    recv = torch.empty((P, total), dtype=torch.uint8, device=DEV)
+    for r in range(P):
+        lo, hi = fr.search.shard_range(G, r, P)
+        sv, iv = fr.search.packed_views(recv[r], Q, k)
+        fr.search.Matcher(g[lo:hi], idx_offset=lo, k=k).search_into(q, sv, iv)
+    sm = fr.search.ShardedMatcher(g[:fr.search.shard_range(G, 0, P)[1]], G, 0, P, k=k)
+    out_s = torch.empty((Q, k), dtype=torch.float32, device=DEV)
+    out_i = torch.empty((Q, k), dtype=torch.int64, device=DEV)
+    sm._merge(recv, Q, out_s, out_i)
+    assert torch.equal(out_i, i1) and torch.equal(out_s, s1)

@@ -111,7 +111,7 @@ def _gloo_body(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import search as osr
-    G, Q, k = 1500, 16, 5
+    G, Q, k = 1500, 40, 5
     g = osr.bf16_bits_to_f32(osr.gallery_rows(7, 11, 0, G, G, 4))
     qs = osr.bf16_bits_to_f32(osr.query_rows(11, 0, Q))
     lo, hi = fr.search.shard_range(G, rank, world)
@@ -119,7 +119,26 @@ def _gloo_body(rank, world, port, q):
     gs, gi = fr.search.all_gather_topk(torch.from_numpy(s).float(), torch.from_numpy(i))
     ms, mi = osr.merge_topk(gs.numpy(), gi.numpy(), k)
     fs, fi, _ = osr.topk_cosine(qs, g, k)
-    q.put((rank, bool(np.array_equal(mi, fi)), tuple(gs.shape)))
+    ok = bool(np.array_equal(mi, fi))
+    # the pipelined form ShardedMatcher runs: packed messages, one async all_gather per chunk of 24 queries
+    # (two chunks, the second ragged), chunk t merged while chunk t+1 is searched
+    calls = []
+
+    def local_search(qc, sv, iv):
+        cs, ci, _ = osr.topk_cosine(qc.numpy(), g[lo:hi], k, idx_offset=lo)
+        sv.copy_(torch.from_numpy(cs).float()); iv.copy_(torch.from_numpy(ci))
+        calls.append(("search", len(qc)))
+
+    def merge(recv, Qc, out_s, out_i):
+        views = [fr.search.packed_views(recv[p], Qc, k) for p in range(world)]
+        cs, ci = osr.merge_topk(np.stack([v[0].numpy() for v in views]), np.stack([v[1].numpy() for v in views]), k)
+        out_s.copy_(torch.from_numpy(cs).float()); out_i.copy_(torch.from_numpy(ci))
+        calls.append(("merge", Qc))
+
+    ps, pi = fr.search.exchange_topk_chunks(torch.from_numpy(qs), k, 24, world, None, local_search, merge)
+    ok = ok and bool(np.array_equal(pi.numpy(), fi)) and bool(np.array_equal(ps.numpy(), ms.astype(np.float32)))
+    ok = ok and calls == [("search", 24), ("search", 16), ("merge", 24), ("merge", 16)]     # chunk 0 merges after chunk 1's search
+    q.put((rank, ok, tuple(gs.shape)))
     dist.destroy_process_group()
 
 
@@ -133,7 +152,45 @@ def test_sharded_exchange_world_size_2_gloo():
     [p.start() for p in procs]
     res = [q.get(timeout=120) for _ in procs]
     [p.join(60) for p in procs]
-    assert all(ok for _, ok, _ in res) and all(shape == (2, 16, 5) for _, _, shape in res)
+    assert all(ok for _, ok, _ in res) and all(shape == (2, 40, 5) for _, _, shape in res), res
+
+
+def test_bench_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` without a rank environment must start two ranks itself (fresh children through
+    torch.distributed.run, 127.0.0.1 rendezvous) and shard the 100 M-row gallery of BASELINE.json configs[4] between
+    them.  --rendezvous-only stops after the ranks have found each other (gloo here: no GPU in this container)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                               # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == [0, 1]
+    assert d["search"] == {"gallery_rows": 100_000_000, "shards": [[0, 50_000_000], [50_000_000, 100_000_000]]}
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rendezvous-only"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["search"]["shards"] == [[0, 10_000_000]]
+
+
+def test_cpu_matcher_baseline_agrees_with_the_checker():
+    """bench.py times oracle/search.py:topk_cosine_fp32_chunked as the matcher's CPU baseline; it must compute the
+    same search as the float64 checker (topk_cosine) wherever the scores are separated by more than fp32 noise."""
+    from oracle import search as osr
+    g = osr.bf16_bits_to_f32(osr.gallery_rows(7, 11, 0, 20000, 20000, 8)).astype(np.float64)
+    q = osr.bf16_bits_to_f32(osr.query_rows(11, 0, 64)).astype(np.float64)
+    g = (g / np.linalg.norm(g, axis=1, keepdims=True)).astype(np.float32)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    s, i = osr.topk_cosine_fp32_chunked(torch.from_numpy(q), torch.from_numpy(g), 5, chunk=3000)
+    os_, oi, gap = osr.topk_cosine(q, g, 5)
+    assert np.abs(s.numpy() - os_).max() <= 1e-5
+    seps = np.minimum(np.abs(np.diff(os_, axis=1)).min(axis=1), gap)
+    clear = seps > 1e-5
+    assert clear.sum() >= 32 and np.array_equal(i.numpy()[clear], oi[clear])
+    assert [int(v) for v in i[:8, 0]] == [osr.plant_row(t, 20000, 8) for t in range(8)]
 
 
 def test_custom_ops_registered_and_refuse_cpu():
