@@ -55,6 +55,8 @@ _SIGS = {
     "fr_topk_workspace_bytes": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_size_t)]),
     "fr_topk_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "fr_topk_search_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "fr_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
     "fr_topk_merge_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -562,6 +562,50 @@ extern "C" int fr_topk_search(const uint16_t* q, const uint16_t* g, int64_t Q, i
     return search_run(q, g, Q, G, k, idx_offset, out_scores, out_idx, workspace, stream);
 }
 
+// ---- the entry point that allocates nothing ------------------------------------------------------------------
+// fr_topk_search_noalloc keeps the partial top-k lists (the only scratch buffer of the search: what
+// fr_topk_search takes as `workspace`) in this file-scope device array.  In host code the NAME `scratch` is only a
+// stand-in for the symbol, not a device address: the address of each GPU's copy is asked for once per device with
+// hipGetSymbolAddress and kept in scratch_ptr[]; kernels, like everything else on the host side, only ever see
+// that pointer.
+#define FR_STATIC_SCRATCH_BYTES (32u << 20)
+static __device__ __align__(256) unsigned char scratch[FR_STATIC_SCRATCH_BYTES];
+
+static int search_static_scratch(void** out) {
+    static std::mutex mu;
+    static void* scratch_ptr[64] = {nullptr};
+    int dev = 0;
+    FR_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) FR_FAIL(FR_ERR_UNSUPPORTED, "fr_topk_search_noalloc: device index beyond 63");
+    std::lock_guard<std::mutex> lock(mu);
+    if (!scratch_ptr[dev]) {
+        void* p = nullptr;
+        FR_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));       // the current device's copy of the array
+        if (!p) FR_FAIL(FR_ERR_HIP, "fr_topk_search_noalloc: hipGetSymbolAddress returned a null address");
+        scratch_ptr[dev] = p;
+    }
+    *out = scratch_ptr[dev];
+    return FR_OK;
+}
+
+extern "C" int fr_topk_search_noalloc(const uint16_t* q, const uint16_t* g, int64_t Q, int64_t G, int d, int k,
+                                      int64_t idx_offset, float* out_scores, int64_t* out_idx, void* stream) {
+    void* ws = nullptr;
+    { const int rc = search_static_scratch(&ws); if (rc) return rc; }      // first call on a device: looks the array up
+    { const int rc = search_set_lds_limits(); if (rc) return rc; }
+    if (Q == 0) return FR_OK;                                              // set-up only (e.g. before a graph capture)
+    { const int rc = search_check_args(q, g, Q, G, d, k, out_scores, out_idx); if (rc) return rc; }
+    size_t need = 0;
+    fr_topk_workspace_bytes(Q, G, k, &need);
+    if (need > FR_STATIC_SCRATCH_BYTES) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "fr_topk_search_noalloc: this search needs %zu bytes of partial lists, the static scratch holds %u "
+                 "(use fr_topk_search with a workspace)", need, FR_STATIC_SCRATCH_BYTES);
+        FR_FAIL(FR_ERR_WORKSPACE, msg);
+    }
+    return search_run(q, g, Q, G, k, idx_offset, out_scores, out_idx, ws, stream);
+}
+
 extern "C" int fr_topk_merge(const float* scores, const int64_t* idx, int P, int64_t Q, int k,
                              float* out_scores, int64_t* out_idx, void* stream) {
     if (!scores || !idx || P < 1 || Q <= 0 || k < 1 || k > SEARCH_KMAX) FR_FAIL(FR_ERR_ARG, "fr_topk_merge: bad arguments");

@@ -165,6 +165,17 @@ int fr_topk_workspace_bytes(int64_t Q, int64_t G, int k, size_t* out_bytes);
 int fr_topk_search(const uint16_t* q, const uint16_t* g, int64_t Q, int64_t G, int d, int k,
                    int64_t idx_offset, float* out_scores, int64_t* out_idx,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* No counterpart in the reference.  For callers that cannot allocate device memory around a search (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): fr_topk_search without the workspace
+ * argument.  The partial top-k lists live in a 32 MiB file-scope device array of the library (one copy per GPU,
+ * held until the process ends); the call itself makes no hipMalloc / hipFree.  Results are identical to
+ * fr_topk_search.  FR_ERR_WORKSPACE when fr_topk_workspace_bytes(Q,G,k) exceeds 32 MiB (with the default tuning
+ * the largest need is 25.1 MB at k = 8, 15.7 MB at k = 5, for any Q and G; only the FR_SEARCH_BLOCKS /
+ * FR_SEARCH_QCHUNK tuning variables can push it beyond).  Q == 0 performs the one-time per-device set-up only
+ * (address look-up of the array, kernel attributes) -- do that once before capturing a graph.  All calls on one GPU
+ * share that GPU's array: calls that can overlap on one GPU (two streams, two host threads) race; serialise them. */
+int fr_topk_search_noalloc(const uint16_t* q, const uint16_t* g, int64_t Q, int64_t G, int d, int k,
+                           int64_t idx_offset, float* out_scores, int64_t* out_idx, void* stream);
 /* Merge P per-shard results (scores [P,Q,k], idx [P,Q,k], e.g. after an RCCL all-gather) into the
  * global top-k [Q,k]; deterministic: descending score, ties to the lower global index. */
 int fr_topk_merge(const float* scores, const int64_t* idx, int P, int64_t Q, int k,
