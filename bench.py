@@ -356,7 +356,19 @@ def main():
     torch.cuda.set_device(dev)
     dist_on = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ        # under torchrun even a single rank goes through RCCL
     if dist_on:
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout carries the one JSON
+        # line, so file descriptor 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            torch.distributed.init_process_group("nccl", device_id=dev)
+            torch.distributed.barrier()
+            torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
     import face_recognition_amd as fr
 
     torch.manual_seed(0)

@@ -415,6 +415,163 @@ __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
         if (e < a.k) { a.part_s[base + e] = ts[e]; a.part_i[base + e] = ti[e]; }
 }
 
+// ---- resident queries on v_mfma_f32_16x16x32_bf16 -------------------------------------------------------------
+// Same structure as search_rq_kernel (queries as B fragments in registers, 64-row gallery tiles through LDS, one
+// wait + barrier per tile), on the 16x16x32 MFMA shape: the micro-architecture guide measures bf16 loops on random
+// data at ~1.12-1.15x the FLOP/s of the 32x32x16 shape at equal cycles per FLOP, because the chip holds a higher
+// clock under that instruction.  Per wave and tile: 16 k-steps x (4 row blocks of 16 gallery rows) x (2 column
+// blocks of 16 queries) = 128 MFMAs of 16 cycles; 64 A-fragment reads (ds_read_b128), as before; 8 accumulators
+// of 4 registers.  Accumulator layout: lane l holds column (query) l & 15 and rows 4 * (l >> 4) + r, so a query's
+// 64 scores of a tile are spread over 4 lanes (16 each): 4 candidate lists per query and split, and every lane
+// keeps two lists (one per column block).
+#define RQ16_LISTS 4
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <int KK>
+__global__ __launch_bounds__(512, 1) void search_rq16_kernel(SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int c16 = lane & 15, kg = lane >> 4;
+    const long q0 = (long)blockIdx.x * RQ_QB;
+    const int split = blockIdx.y;
+    const long tile_begin = (long)split * a.tiles_per_split;
+    const long ntiles_all = (a.G + RQ_GT - 1) / RQ_GT;
+    const long tile_end = min(tile_begin + a.tiles_per_split, ntiles_all);
+
+    float ts[2][KK]; int ti[2][KK];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int e = 0; e < KK; ++e) { ts[cb][e] = -INFINITY; ti[cb][e] = 0x7FFFFFFF; }
+
+    // gallery tile -> LDS exactly as in search_rq_kernel: physical 16-byte piece l of row r holds logical piece l ^ (r & 15)
+    const unsigned char* gbase = reinterpret_cast<const unsigned char*>(a.g);
+    const int off_even = (lane ^ wave) << 4, off_odd = (lane ^ (wave | 8)) << 4;
+    auto stage = [&](long tile, int buf) {
+#pragma unroll
+        for (int j = 0; j < RQ_GT / 8; ++j) {
+            const int r = wave + 8 * j;
+            const long gr = min(tile * RQ_GT + r, a.G - 1);
+            const unsigned char* src = gbase + gr * (SEARCH_D * 2) + ((j & 1) ? off_odd : off_even);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(smem + buf * RQ_TILE_BYTES + r * 1024), 16, 0, 0);
+        }
+    };
+    if (tile_begin < tile_end) stage(tile_begin, 0);
+
+    // B fragments of this lane's two queries (column c16 of column blocks 0 and 1): k = 32 s + 8 kg + j
+    bf16x8 bq[2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const long qr = min(q0 + wave * 32 + cb * 16 + c16, a.Q - 1);
+        const bf16x8* src = reinterpret_cast<const bf16x8*>(a.q + qr * SEARCH_D + 8 * kg);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) bq[cb][s] = src[4 * s];
+    }
+    // A fragment of row block rb, k-step s: row rb*16 + c16, logical piece 4 s + kg -> physical (4 s + kg) ^ c16
+    const int abase = c16 * 1024 + ((kg ^ c16) << 4);
+
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+    u32x4 af[2][4];
+    unsigned ka[4];                                        // LDS address of k-step s: ka[s & 3] + (s >> 2) * 256 (+ rb * 16384)
+    auto rd4 = [](auto SC, unsigned addr, u32x4& d0, u32x4& d1, u32x4& d2, u32x4& d3) {
+        constexpr int s_ = decltype(SC)::value;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d0) : "v"(addr), "n"((s_ >> 2) * 256) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d1) : "v"(addr), "n"((s_ >> 2) * 256 + 16384) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d2) : "v"(addr), "n"((s_ >> 2) * 256 + 32768) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d3) : "v"(addr), "n"((s_ >> 2) * 256 + 49152) : "memory");
+    };
+    if (tile_begin + 1 < tile_end) stage(tile_begin + 1, 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ka[j] = lds0 + (abase ^ (j << 6));
+    if (tile_begin < tile_end) rd4(std::integral_constant<int, 0>{}, ka[0], af[0][0], af[0][1], af[0][2], af[0][3]);
+    int buf = 0;
+#pragma unroll 1
+    for (long tile = tile_begin; tile < tile_end; ++tile) {
+        auto step = [&](auto SC) {
+            constexpr int s = decltype(SC)::value;
+            if constexpr (s + 1 < 16) {
+                rd4(std::integral_constant<int, s + 1>{}, ka[(s + 1) & 3], af[(s + 1) & 1][0], af[(s + 1) & 1][1], af[(s + 1) & 1][2], af[(s + 1) & 1][3]);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[s & 1][0]), "+v"(af[s & 1][1]), "+v"(af[s & 1][2]), "+v"(af[s & 1][3]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[s & 1][0]), "+v"(af[s & 1][1]), "+v"(af[s & 1][2]), "+v"(af[s & 1][3]));
+            }
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[s & 1][rb]), bq[cb][s], acc[rb][cb], 0, 0, 0);
+        };
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{}); step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+        step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+        step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's rows of the next tile have landed
+        __syncthreads();                                         // ... everyone's; and everyone is done reading this tile
+        if (tile + 2 < tile_end) stage(tile + 2, buf);
+        if (tile + 1 < tile_end) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ka[j] = lds0 + (buf ^ 1) * RQ_TILE_BYTES + (abase ^ (j << 6));
+            rd4(std::integral_constant<int, 0>{}, ka[0], af[0][0], af[0][1], af[0][2], af[0][3]);
+        }
+        // ---- selection: accumulator rows = gallery rows tile*64 + rb*16 + 4*kg + r, column = this lane's query of block cb
+        const long gb = tile * RQ_GT;
+        const bool partial = gb + RQ_GT > a.G;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            if (partial) {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (gb + rb * 16 + 4 * kg + r >= a.G) acc[rb][cb][r] = -INFINITY;
+            }
+            float mx = acc[0][cb][0];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[rb][cb][r]);
+            if (__any(mx > ts[cb][KK - 1])) {
+                const int g0 = (int)gb + 4 * kg;
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float sc = acc[rb][cb][r];
+                        if (sc > ts[cb][KK - 1]) {
+                            int gi = g0 + rb * 16 + r;
+#pragma unroll
+                            for (int e = 0; e < KK; ++e) {
+                                if (sc > ts[cb][e]) {
+                                    const float t = ts[cb][e]; ts[cb][e] = sc; sc = t;
+                                    const int u = ti[cb][e]; ti[cb][e] = gi; gi = u;
+                                }
+                            }
+                        }
+                    }
+            }
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) acc[rb][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        buf ^= 1;
+    }
+
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const long qrow = q0 + wave * 32 + cb * 16 + c16;
+        const long base = (((long)split * RQ16_LISTS + kg) * a.Qpad + qrow) * a.k;
+        for (int e = 0; e < KK; ++e)
+            if (e < a.k) { a.part_s[base + e] = ts[cb][e]; a.part_i[base + e] = ti[cb][e]; }
+    }
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it once for each device a
 // search runs on (a process-wide flag made the first search on a second GPU fail at launch), under a lock so that
 // host threads searching on different streams do not race on the flags.
@@ -430,6 +587,8 @@ static int search_set_lds_limits() {
     FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_rq_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, rq));
     FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_rq_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, rq));
     FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_rq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, rq));
+    FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_rq16_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, rq));
+    FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_rq16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, rq));
     FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
     FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
     FR_HIP_CHECK(hipFuncSetAttribute((const void*)search_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, sl));
@@ -467,6 +626,10 @@ static bool search_use_rq() {
     const char* s = getenv("FR_SEARCH_RQ");              // default on; 0 = search_kernel
     return !s || atoi(s) != 0;
 }
+static bool search_use_mfma16() {
+    const char* s = getenv("FR_SEARCH_MFMA");            // default 16: v_mfma_f32_16x16x32_bf16; 32 = the 32x32x16 form
+    return !s || atoi(s) != 32;
+}
 static long search_qchunk() {
     const char* e = getenv("FR_SEARCH_QCHUNK");          // tuning
     return e && atol(e) >= 256 ? atol(e) / 256 * 256 : (search_use_rq() ? 32768L : 16384L);
@@ -485,7 +648,7 @@ extern "C" int fr_topk_workspace_bytes(int64_t Q, int64_t G, int k, size_t* out_
         search_geometry(qc, G, &ns, &tps, &qpad);
         need = std::max(need, (size_t)ns * SEARCH_LISTS * qpad * k * 8 + 512);
         search_geometry_rq(qc, G, &ns, &tps, &qpad);            // either form may run (FR_SEARCH_RQ)
-        need = std::max(need, (size_t)ns * RQ_LISTS * qpad * k * 8 + 512);
+        need = std::max(need, (size_t)ns * RQ16_LISTS * qpad * k * 8 + 512);     // RQ16_LISTS >= RQ_LISTS
     }
     *out_bytes = need;
     return FR_OK;
@@ -519,7 +682,8 @@ static int search_run(const uint16_t* q, const uint16_t* g, int64_t Q, int64_t G
     const bool rq = search_use_rq();
     if (rq) search_geometry_rq(Q, G, &a.nsplit, &a.tiles_per_split, &a.Qpad);
     else search_geometry(Q, G, &a.nsplit, &a.tiles_per_split, &a.Qpad);
-    const int lists = rq ? RQ_LISTS : SEARCH_LISTS;
+    const bool m16 = rq && k <= 5 && search_use_mfma16();      // k = 6..8 would spill registers in the 16x16x32 form
+    const int lists = rq ? (m16 ? RQ16_LISTS : RQ_LISTS) : SEARCH_LISTS;
     unsigned char* ws = reinterpret_cast<unsigned char*>(align_up((size_t)workspace, 256));
     const size_t nel = (size_t)a.nsplit * lists * a.Qpad * k;
     a.part_s = reinterpret_cast<float*>(ws);
@@ -528,9 +692,14 @@ static int search_run(const uint16_t* q, const uint16_t* g, int64_t Q, int64_t G
         const size_t lds = 2 * RQ_TILE_BYTES;
         dim3 grid((unsigned)(a.Qpad / RQ_QB), (unsigned)a.nsplit);
         { const int rc = search_set_lds_limits(); if (rc) return rc; }
-        if (k == 1) hipLaunchKernelGGL((search_rq_kernel<1>), grid, dim3(512), lds, st, a);
-        else if (k <= 5) hipLaunchKernelGGL((search_rq_kernel<5>), grid, dim3(512), lds, st, a);
-        else hipLaunchKernelGGL((search_rq_kernel<8>), grid, dim3(512), lds, st, a);
+        if (m16) {
+            if (k == 1) hipLaunchKernelGGL((search_rq16_kernel<1>), grid, dim3(512), lds, st, a);
+            else hipLaunchKernelGGL((search_rq16_kernel<5>), grid, dim3(512), lds, st, a);
+        } else {
+            if (k == 1) hipLaunchKernelGGL((search_rq_kernel<1>), grid, dim3(512), lds, st, a);
+            else if (k <= 5) hipLaunchKernelGGL((search_rq_kernel<5>), grid, dim3(512), lds, st, a);
+            else hipLaunchKernelGGL((search_rq_kernel<8>), grid, dim3(512), lds, st, a);
+        }
         FR_LAUNCH_CHECK("search_rq_kernel");
         hipLaunchKernelGGL((topk_select_kernel<int>), dim3((unsigned)((Q + 127) / 128)), dim3(128), 0, st,
                            a.part_s, a.part_i, a.nsplit * lists, a.Qpad * (long)k, a.Qpad * (long)k, (long)Q, k, (long)idx_offset,

@@ -508,19 +508,24 @@ def test_topk_search_parity(Q, G):
 
 
 def test_resident_query_search_equals_slice_staged_search(monkeypatch):
-    """search_rq_kernel (queries in registers, whole gallery tiles in LDS; the default) against search_kernel
-    (FR_SEARCH_RQ=0): both accumulate the 32 k-steps of a score in the same order, so scores and indices must be
-    identical bit for bit -- ragged query count over two 256-query blocks, a gallery that ends inside a tile, planted
-    near-duplicates, k = 5 and k = 8."""
+    """The three forms of the search kernel -- search_rq16_kernel (queries in registers, 16x16x32 MFMA; the default for
+    k <= 5), search_rq_kernel (the same on 32x32x16 MFMA; FR_SEARCH_MFMA=32, and always for k = 6..8) and search_kernel
+    (slice-staged, FR_SEARCH_RQ=0) -- accumulate a score over K = 512 in the same order, so scores and indices must be
+    identical bit for bit: ragged query count over two 256-query blocks, a gallery that ends inside a tile, planted
+    near-duplicates, k = 1, 5 and 8."""
     G, Q = 50021, 300
     g = fr.search.synth_rows(7, 0, G, DEV, plant_seed=11, n_plant=16, n_gallery_total=G)
     q = fr.search.synth_rows(11, 0, Q, DEV)
-    for k in (5, 8):
+    for k in (1, 5, 8):
         monkeypatch.setenv("FR_SEARCH_RQ", "1")
+        monkeypatch.setenv("FR_SEARCH_MFMA", "16")
+        s16, i16 = fr.search.Matcher(g, k=k).search(q)
+        monkeypatch.setenv("FR_SEARCH_MFMA", "32")
         s1, i1 = fr.search.Matcher(g, k=k).search(q)
         monkeypatch.setenv("FR_SEARCH_RQ", "0")
         s0, i0 = fr.search.Matcher(g, k=k).search(q)
         assert torch.equal(i1, i0) and torch.equal(s1, s0)
+        assert torch.equal(i16, i0) and torch.equal(s16, s0)
 
 
 def test_topk_search_edge_cases():
