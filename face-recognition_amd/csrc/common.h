@@ -184,6 +184,29 @@ FR_DEV void stage_flush(const unsigned char* stage, int pitch, int lane, bf16* y
     __builtin_amdgcn_wave_barrier();
 }
 
+// fp32 outputs (fp32 plans) take the same route: a lane's 16 channels are 64 B, written as 16-byte pieces that sit
+// cout * 4 bytes apart from the neighbour lane's -- the isolated-piece pattern again (measured: the fp32 1x1 convs
+// wrote at 2.8 TB/s).  Tile rows are then ncol * 4 bytes.
+FR_DEV void stage_put_f32(unsigned char* stage, int pitch, int row, int col, const Vec8f& v) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v.v[i]; b[i] = v.v[4 + i]; }
+    *reinterpret_cast<f32x4*>(stage + row * pitch + col * 4) = a;
+    *reinterpret_cast<f32x4*>(stage + row * pitch + col * 4 + 16) = b;
+}
+FR_DEV void stage_flush_f32(const unsigned char* stage, int pitch, int lane, float* y, long ystride, int ncol, int rows) {
+    const int cr = ncol >> 2;                                   // 16-byte chunks per row (<= 32)
+    const unsigned magic = (65536u + cr - 1) / cr;
+    const int total = rows * cr;
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < total; c += 64) {
+        const int row = (int)(((unsigned)c * magic) >> 16), ch = c - row * cr;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * pitch + ch * 16);
+        *reinterpret_cast<u32x4*>(y + row * ystride + ch * 4) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Common epilogue arguments of the GEMM-shaped conv kernels.
 struct EpiArgs {
     const float* bias;      // [cout_pad32] folded bias (zeros when absent)
@@ -247,5 +270,32 @@ FR_DEV void epilogue_stage(const f32x16& acc, const EpiArgs& e, long m, int c0, 
             for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
         }
         stage_put(stage, pitch, row, col0 + 8 * g, v);
+    }
+}
+
+// epilogue_stage for fp32 outputs: same arithmetic as epilogue_store<float>, result into the wave's fp32 staging tile.
+FR_DEV void epilogue_stage_f32(const f32x16& acc, const EpiArgs& e, long m, int c0, bool m_ok,
+                               unsigned char* stage, int pitch, int row, int col0) {
+    if (!m_ok) return;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        int c = c0 + 8 * g;
+        if (c >= e.cout) continue;
+        Vec8f v;
+        f32x4 b0 = *reinterpret_cast<const f32x4*>(e.bias + c);
+        f32x4 b1 = *reinterpret_cast<const f32x4*>(e.bias + c + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v.v[i] = acc[8 * g + i] + b0[i]; v.v[4 + i] = acc[8 * g + 4 + i] + b1[i]; }
+        if (e.act == FR_ACT_PRELU) {
+            prelu8(v, *reinterpret_cast<const f32x4*>(e.slope + c), *reinterpret_cast<const f32x4*>(e.slope + c + 4));
+        } else if (e.act != FR_ACT_NONE) {
+            act8(v, e.act, nullptr);
+        }
+        if (e.residual) {
+            Vec8f r = load8(reinterpret_cast<const float*>(e.residual) + m * (long)e.cout + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
+        }
+        stage_put_f32(stage, pitch, row, col0 + 8 * g, v);
     }
 }

@@ -332,8 +332,12 @@ static int launch_pw_proj(const PwArgs& a, hipStream_t st) {
 // KSM: max k-steps.  SG: n-tiles staged together for the coalesced write-back; SG = NTB when the
 // block covers whole output rows (one column group), so that the 32-pixel tile leaves as ONE linear
 // run (a trailing 8- or 16-channel group of its own would again write 16/32-byte pieces).
-template <typename TOut, int NTB, int MT, int KSM = 8 / MT, int SG = (NTB < 2 ? NTB : 2)>
+template <typename TIn, typename TOut, int NTB, int MT, int KSM = 8 / MT, int SG = (NTB < 2 ? NTB : 2)>
 __global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) {
+    // TIn = float (fp32 plans): fp32 activations are split into bf16 hi + lo on load and every product is three
+    // MFMA passes against the hi/lo weight fragments, in the order pw_gemm_kernel uses (same bits either way)
+    constexpr bool SPLIT = std::is_same<TIn, float>::value;
+    constexpr int NS = SPLIT ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
@@ -342,13 +346,13 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) 
     const int t0 = bg * NTB;
     const int nt = min(NTB, a.NT - t0);
     const int KS = a.KS;
-    bf16x8* wl = reinterpret_cast<bf16x8*>(smem);                         // [nt][KS][64]
-    float* bl = reinterpret_cast<float*>(smem + (size_t)NTB * KS * 1024);  // [NTB*32] bias, then slope
+    bf16x8* wl = reinterpret_cast<bf16x8*>(smem);                         // [nt][KS][NS][64]
+    float* bl = reinterpret_cast<float*>(smem + (size_t)NTB * KS * NS * 1024);  // [NTB*32] bias, then slope
     {
         // LDS-DMA: weights as 1-KiB fragments, bias and slopes as 16-byte units; one wait for all
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-        const u32x4* src = reinterpret_cast<const u32x4*>(a.w) + (size_t)t0 * KS * 64;
-        for (int f = wave_u; f < nt * KS; f += 4)
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.w) + (size_t)t0 * KS * NS * 64;
+        for (int f = wave_u; f < nt * KS * NS; f += 4)
             __builtin_amdgcn_global_load_lds((pw_glb_ptr_t)(src + f * 64 + lane), (pw_lds_ptr_t)(smem + f * 1024), 16, 0, 0);
         if (wave_u == 0 && lane < nt * 8)
             __builtin_amdgcn_global_load_lds((pw_glb_ptr_t)(a.e.bias + t0 * 32 + lane * 4), (pw_lds_ptr_t)(bl), 16, 0, 0);
@@ -357,40 +361,31 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    const bf16* X = reinterpret_cast<const bf16*>(a.x);
+    const TIn* X = reinterpret_cast<const TIn*>(a.x);
     const TOut* R = reinterpret_cast<const TOut*>(a.e.residual);
     TOut* Y = reinterpret_cast<TOut*>(a.e.y);
     const long per_iter = 128L * MT;
     const long n_iter = (a.M + per_iter - 1) / per_iter;
     const int cout = a.e.cout;
-    constexpr bool STAGED = std::is_same<TOut, bf16>::value;
-    constexpr int PITCH = stage_pitch(SG * 64);
-    unsigned char* stage = smem + (size_t)NTB * KS * 1024 + (size_t)NTB * 256 + (size_t)wave * 32 * PITCH;
+    constexpr bool STAGED = true;                          // bf16 and fp32 outputs both leave through a wave-private LDS tile
+    constexpr bool OUT32 = std::is_same<TOut, float>::value;
+    constexpr int PITCH = stage_pitch(SG * 32 * (int)sizeof(TOut));
+    unsigned char* stage = smem + (size_t)NTB * KS * NS * 1024 + (size_t)NTB * 256 + (size_t)wave * 32 * PITCH;
 
     for (long it = bx; it < n_iter; it += pg.gx) {
         const long mbase = it * per_iter + (long)wave * 32 * MT + p;
-        bf16x8 xf[MT][KSM];
+        XFrag<TIn> xf[MT][KSM];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const long m = mbase + mt * 32;
             const long mc = m < a.M ? m : a.M - 1;
-            const bf16* xrow = X + mc * (long)a.K;
+            const TIn* xrow = X + mc * (long)a.K;
             const float* serow = a.se ? a.se + (mc / a.HW) * (long)a.K : nullptr;
 #pragma unroll
             for (int s = 0; s < KSM; ++s) {
                 const int kk = s * 16 + 8 * h;
-                if (s < KS && kk < a.K) {
-                    if (serow) {
-                        Vec8f x = load8(xrow + kk), sc = load8(serow + kk);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) x.v[i] *= sc.v[i];
-                        xf[mt][s] = to_frag(x);
-                    } else {
-                        xf[mt][s] = *reinterpret_cast<const bf16x8*>(xrow + kk);
-                    }
-                } else {
-                    xf[mt][s] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                }
+                if (s < KS && kk < a.K) xf[mt][s].load(xrow + kk, serow ? serow + kk : nullptr);
+                else xf[mt][s].zero();
             }
         }
 #pragma unroll
@@ -405,7 +400,14 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) 
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
                     for (int s = 0; s < KSM; ++s)
-                        if (s < KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[(t * KS + s) * 64 + lane], xf[mt][s], acc, 0, 0, 0);
+                        if (s < KS) {
+                            const bf16x8 wh = wl[((t * KS + s) * NS) * 64 + lane];
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[mt][s].hi, acc, 0, 0, 0);
+                            if constexpr (SPLIT) {
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[mt][s].lo, acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[((t * KS + s) * NS + 1) * 64 + lane], xf[mt][s].hi, acc, 0, 0, 0);
+                            }
+                        }
                     if (m_ok) {
 #pragma unroll
                         for (int g = 0; g < 2; ++g) {
@@ -424,8 +426,8 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) 
 #pragma unroll
                                     for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
                                 }
-                                if constexpr (STAGED) stage_put(stage, PITCH, p, cl - (t / SG) * SG * 32, v);
-                                else store8(Y + off, v);
+                                if constexpr (OUT32) stage_put_f32(stage, PITCH, p, cl - (t / SG) * SG * 32, v);
+                                else stage_put(stage, PITCH, p, cl - (t / SG) * SG * 32, v);
                             }
                         }
                     }
@@ -434,9 +436,14 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) 
                             const int tg = (t / SG) * SG;
                             const long tile0 = m - p;                          // first pixel of this wave's tile
                             const long left = a.M - tile0;
-                            if (left > 0)
-                                stage_flush(stage, PITCH, lane, reinterpret_cast<bf16*>(Y) + tile0 * cout + (t0 + tg) * 32, cout,
-                                            min(SG * 32, cout - (t0 + tg) * 32), left < 32 ? (int)left : 32);
+                            if (left > 0) {
+                                if constexpr (OUT32)
+                                    stage_flush_f32(stage, PITCH, lane, reinterpret_cast<float*>(Y) + tile0 * cout + (t0 + tg) * 32, cout,
+                                                    min(SG * 32, cout - (t0 + tg) * 32), left < 32 ? (int)left : 32);
+                                else
+                                    stage_flush(stage, PITCH, lane, reinterpret_cast<bf16*>(Y) + tile0 * cout + (t0 + tg) * 32, cout,
+                                                min(SG * 32, cout - (t0 + tg) * 32), left < 32 ? (int)left : 32);
+                            }
                         }
                     }
                 }
@@ -541,6 +548,15 @@ int launch_fc(bool in_f32, const PwArgs& a, hipStream_t st) {
 
 void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks) {
     const int ns = in_f32 ? 2 : 1;
+    if (in_f32 && KS <= 8 && !(getenv("FR_PW_F32_STREAM") && atoi(getenv("FR_PW_F32_STREAM")) == 0)) {
+        // fp32 plans, K <= 128: the streaming kernel with the whole hi+lo weight slab of the block's n-tiles resident
+        // (n-tiles x k-steps x 2 KB), no k-chunk restaging
+        int b = 1;
+        while (b * 2 <= NT && b * 2 <= 4 && b * 2 * KS * 2 <= 32) b *= 2;      // <= 32 KB of weights + 35 KB of output staging: two blocks per CU
+        *ntb = b;
+        *chunk_ks = KS;
+        return;
+    }
     // bf16, 128 < K <= 256: two n-tiles per block keep the whole weight slab (<= 32 KB) resident,
     // so the streaming kernel applies (no k-chunk restaging); the activations are re-read from L2
     // by the extra column groups.
@@ -558,9 +574,11 @@ void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks) {
     *chunk_ks = ck;
 }
 
-template <typename TOut, int NTB, int SG>
+template <typename TIn, typename TOut, int NTB, int SG>
 static int launch_pw_stream_sg(const PwArgs& a, hipStream_t st) {
-    int mt = a.KS <= 2 ? 4 : (a.KS <= 4 ? 2 : (a.KS <= 8 ? 1 : 0));
+    constexpr int NS = std::is_same<TIn, float>::value ? 2 : 1;
+    // pixel tiles per wave: 8 operand fragments per lane in flight for bf16, 4 (hi + lo each) for fp32 up to K = 64
+    int mt = NS == 2 ? (a.KS <= 2 ? 2 : 1) : (a.KS <= 2 ? 4 : (a.KS <= 4 ? 2 : (a.KS <= 8 ? 1 : 0)));
     static const int mt_env = getenv("FR_PW_MT") ? atoi(getenv("FR_PW_MT")) : 0;           // tuning: cap on pixel tiles per wave
     if (mt_env > 0 && mt > mt_env) mt = mt_env;
     const long per_iter = 128L * (mt ? mt : 1);
@@ -573,24 +591,31 @@ static int launch_pw_stream_sg(const PwArgs& a, hipStream_t st) {
     const long want = std::max<long>(8, cdiv(total_blocks, ng));
     const PwGrid pg{(int)std::min<long>(n_iter, want), ng};
     dim3 grid(pw_grid_blocks(pg.gx, pg.ng));
-    size_t lds = (size_t)NTB * a.KS * 1024 + (size_t)NTB * 256;
-    if (std::is_same<TOut, bf16>::value) lds += 4 * 32 * (size_t)stage_pitch(SG * 64);
-#define FR_PW_GO(MT_, KSM_) do { FR_BIG_LDS((pw_stream_kernel<TOut, NTB, MT_, KSM_, SG>), lds); \
-        hipLaunchKernelGGL((pw_stream_kernel<TOut, NTB, MT_, KSM_, SG>), grid, dim3(256), lds, st, a, pg); } while (0)
-    if (mt == 4) FR_PW_GO(4, 2);
-    else if (mt == 2) FR_PW_GO(2, 4);
-    else if (mt == 1) FR_PW_GO(1, 8);
-    else FR_PW_GO(1, 16);
+    size_t lds = (size_t)NTB * a.KS * NS * 1024 + (size_t)NTB * 256;
+    lds += 4 * 32 * (size_t)stage_pitch(SG * 32 * (int)sizeof(TOut));
+#define FR_PW_GO(MT_, KSM_) do { FR_BIG_LDS((pw_stream_kernel<TIn, TOut, NTB, MT_, KSM_, SG>), lds); \
+        hipLaunchKernelGGL((pw_stream_kernel<TIn, TOut, NTB, MT_, KSM_, SG>), grid, dim3(256), lds, st, a, pg); } while (0)
+    if constexpr (NS == 2) {
+        if (mt == 2) FR_PW_GO(2, 2);
+        else if (a.KS <= 4) FR_PW_GO(1, 4);
+        else FR_PW_GO(1, 8);
+    } else {
+        if (mt == 4) FR_PW_GO(4, 2);
+        else if (mt == 2) FR_PW_GO(2, 4);
+        else if (mt == 1) FR_PW_GO(1, 8);
+        else FR_PW_GO(1, 16);
+    }
 #undef FR_PW_GO
     FR_LAUNCH_CHECK("pw_stream_kernel");
     return FR_OK;
 }
 
-template <typename TOut, int NTB>
+template <typename TIn, typename TOut, int NTB>
 static int launch_pw_stream(const PwArgs& a, hipStream_t st) {
     constexpr int SG2 = NTB < 2 ? NTB : 2;
-    if (NTB > 2 && a.NT <= NTB) return launch_pw_stream_sg<TOut, NTB, NTB>(a, st);     // whole rows in one block
-    return launch_pw_stream_sg<TOut, NTB, SG2>(a, st);
+    if constexpr (std::is_same<TOut, bf16>::value)       // (fp32 tiles of 4 n-tiles would take 67 KB of LDS: two at a time, 256-byte runs)
+        if (NTB > 2 && a.NT <= NTB) return launch_pw_stream_sg<TIn, TOut, NTB, NTB>(a, st);     // whole rows in one block
+    return launch_pw_stream_sg<TIn, TOut, NTB, SG2>(a, st);
 }
 
 template <typename TIn, typename TOut>
@@ -598,9 +623,18 @@ static int launch_pw_t(const PwArgs& a, int ntb, hipStream_t st) {
     if constexpr (std::is_same<TIn, bf16>::value) {
         if (a.KS <= 16 && a.chunk_ks >= a.KS && (a.KS <= 8 || ntb <= 2)) {
             switch (ntb) {
-                case 1: return launch_pw_stream<TOut, 1>(a, st);
-                case 2: return launch_pw_stream<TOut, 2>(a, st);
-                case 4: return launch_pw_stream<TOut, 4>(a, st);
+                case 1: return launch_pw_stream<TIn, TOut, 1>(a, st);
+                case 2: return launch_pw_stream<TIn, TOut, 2>(a, st);
+                case 4: return launch_pw_stream<TIn, TOut, 4>(a, st);
+                default: break;
+            }
+        }
+    } else if constexpr (std::is_same<TOut, float>::value) {
+        if (a.KS <= 8 && a.chunk_ks >= a.KS) {
+            switch (ntb) {
+                case 1: return launch_pw_stream<TIn, TOut, 1>(a, st);
+                case 2: return launch_pw_stream<TIn, TOut, 2>(a, st);
+                case 4: return launch_pw_stream<TIn, TOut, 4>(a, st);
                 default: break;
             }
         }
@@ -628,7 +662,7 @@ const char* pw_kernel_name(bool in_f32, bool out_f32, int K, int cout, bool se, 
     const int KS = cdiv(K, 16), NT = cdiv(cout, 32);
     int ntb, ck;
     pw_pick_tiling(in_f32, NT, KS, &ntb, &ck);
-    if (in_f32) return "pw_gemm_kernel";
+    if (in_f32) return (out_f32 && KS <= 8 && ck >= KS) ? "pw_stream_kernel" : "pw_gemm_kernel";
     if (!out_f32 && KS > 16 && (!se || HW >= 43)) return "pw_proj_kernel";
     if (KS <= 16 && ck >= KS && (KS <= 8 || ntb <= 2)) return "pw_stream_kernel";
     return "pw_gemm_kernel";
