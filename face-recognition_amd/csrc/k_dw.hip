@@ -348,25 +348,29 @@ int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st) {
 }
 
 
-// ---- depthwise + following 1x1 conv in one kernel (bf16) -------------------------------------------
+// ---- depthwise + following 1x1 conv in one kernel ---------------------------------------------------
 // For the early blocks (all channels of a tile fit one block: C <= 128) the depthwise output never
-// goes to HBM: the block keeps its TH x TW x C result as bf16 in LDS (over the input tile, which is
-// dead by then) and multiplies it by the 1x1 weights on MFMA right away -- the pointwise launch and
-// one write + one read of the expanded activation disappear.  Arithmetic is identical to the two
-// separate kernels (same bf16 rounding of the depthwise output, same k order in the MFMA), so the
-// fused and the unfused plan give bit-identical results.
+// goes to HBM: the block keeps its TH x TW x C result in LDS (over the input tile, which is dead by
+// then) and multiplies it by the 1x1 weights on MFMA right away -- the pointwise launch and one
+// write + one read of the expanded activation disappear.  Arithmetic is identical to the separate
+// kernels (same rounding points, same k order and pass order in the MFMAs), so the fused and the
+// unfused plan give bit-identical results.
+// T = bf16: activations bf16, one MFMA pass.  T = float (fp32 plans): activations fp32 in HBM and in the
+// depthwise tile; the depthwise result is split into bf16 hi + lo planes when it is written to LDS and every
+// product is the three passes (w_hi x_hi, w_hi x_lo, w_lo x_hi) of the fp32 1x1 kernels.
 struct DwpArgs {
     DwArgs dw;            // depthwise part (dw.y unused; CBV == C/8, cchunks == 1)
-    const bf16* wp;       // 1x1 weights packed [NT][KS][64][8]
+    const bf16* wp;       // 1x1 weights packed [NT][KS][NS][64][8]
     EpiArgs e;            // 1x1 epilogue: bias, slopes, residual, y, cout, act
     int KS, NT;
     int npx, npx_pad;     // TH*TW and its round-up to 32
-    int pitch;            // bytes per row of the LDS depthwise result
+    int pitch;            // bytes per row of one plane of the LDS depthwise result
+    int off_lo;           // fp32 plans: byte offset of the lo plane
     int off_wp, off_stage;
     int off_pb;           // bias then slopes of the 1x1 conv, [NT*32] floats each
     // optional expand 1x1 conv in front (EXPAND form): dw.x is then unused
-    const bf16* xin;      // block input [N,H,W,Cin]
-    const bf16* we;       // expand weights packed [NTe][KSe][64][8]
+    const void* xin;      // block input [N,H,W,Cin]
+    const bf16* we;       // expand weights packed [NTe][KSe][NS][64][8]
     const float* be;      // expand bias (padded to 32)
     const float* se;      // expand PReLU slopes or NULL
     int act_e, Cin, KSe, NTe;
@@ -375,27 +379,30 @@ struct DwpArgs {
 };
 
 // Expand phase of the fused block: out[pixel][C] = act(W_e . in[pixel][Cin] + b) for every pixel of the staged
-// input tile, written as bf16 in the depthwise tile layout (pitch g.PP vectors per pixel), zero outside the
+// input tile, written in the depthwise tile layout (pitch g.PP vectors per pixel), zero outside the
 // image.  The kernel is bound by instruction issue (one wave per SIMD and block, three blocks per CU), so
 // everything uniform is decided at compile time: k-steps, channel tiles, the activation (ACT < 0: run-time
 // act8) and whether the tile touches the image border at all (MASK).  Weights and bias live in registers.
-template <int KSE, int NTE, int ACT, bool MASK>
+template <typename T, int KSE, int NTE, int ACT, bool MASK>
 FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, const float* bel, const float* sel,
                        int gy0, int gx0, int wave, int lane) {
+    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr int NS = F32 ? 2 : 1;
     const DwArgs& a = x.dw;
     const int IW = g.IW, npin = g.IH * IW;
     const int pe = lane & 31, he = lane >> 5;
     const unsigned char* inl = smem + x.off_in;
-    const int rowb = x.Cin * 2;
-    u32x4* etile = reinterpret_cast<u32x4*>(smem);
-    bf16x8 wv[NTE][KSE];
+    const int rowb = x.Cin * (int)sizeof(T);
+    bf16x8 wv[NTE][KSE][NS];
     f32x4 bb[NTE][4], ss[NTE][4];                     // bias and (PReLU) slopes of this lane's 16 channels per tile
     {
         const bf16x8* wef = reinterpret_cast<const bf16x8*>(smem + x.off_we) + lane;
 #pragma unroll
         for (int t = 0; t < NTE; ++t) {
 #pragma unroll
-            for (int sk = 0; sk < KSE; ++sk) wv[t][sk] = wef[(t * KSE + sk) * 64];
+            for (int sk = 0; sk < KSE; ++sk)
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) wv[t][sk][sp] = wef[((t * KSE + sk) * NS + sp) * 64];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 bb[t][q] = *reinterpret_cast<const f32x4*>(bel + 32 * t + 16 * he + 4 * q);
@@ -412,62 +419,85 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
             const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
             inimg = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
         }
-        bf16x8 xf[KSE];
+        bf16x8 xf[KSE][NS];
 #pragma unroll
         for (int sk = 0; sk < KSE; ++sk) {
             const int kk = 16 * sk + 8 * he;
-            xf[sk] = kk < x.Cin ? *reinterpret_cast<const bf16x8*>(inl + pc * rowb + kk * 2) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (F32) {
+                if (kk < x.Cin) split8(load8(reinterpret_cast<const float*>(inl + pc * rowb) + kk), xf[sk][0], xf[sk][1]);
+                else { xf[sk][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xf[sk][1] = xf[sk][0]; }
+            } else {
+                xf[sk][0] = kk < x.Cin ? *reinterpret_cast<const bf16x8*>(inl + pc * rowb + kk * 2) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
-        u32x4* dst = etile + pix * g.PP + 2 * he;
+        // 8-channel group cg of this pixel sits at (pix * PP + cg) vectors of sizeof(V8<T>) bytes
+        unsigned char* dst = smem + ((size_t)pix * g.PP + 2 * he) * sizeof(V8<T>);
 #pragma unroll
         for (int t = 0; t < NTE; ++t) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int sk = 0; sk < KSE; ++sk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk], xf[sk], acc, 0, 0, 0);
+            for (int sk = 0; sk < KSE; ++sk) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][0], xf[sk][0], acc, 0, 0, 0);
+                if constexpr (F32) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][0], xf[sk][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][1], xf[sk][0], acc, 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg) {
                 const int c = 32 * t + 16 * he + 8 * gg;
                 Vec8f v;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { v.v[i] = acc[8 * gg + i] + bb[t][2 * gg][i]; v.v[4 + i] = acc[8 * gg + 4 + i] + bb[t][2 * gg + 1][i]; }
-                u32x4 r;
                 if constexpr (ACT == FR_ACT_RELU) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) r[i] = pack2bf(relu1(v.v[2 * i]), relu1(v.v[2 * i + 1]));
-                } else {
-                    if constexpr (ACT == FR_ACT_PRELU) {
-                        // slopes from registers: a pointer here makes the compiler branch and load per element
+                    for (int i = 0; i < 8; ++i) v.v[i] = relu1(v.v[i]);
+                } else if constexpr (ACT == FR_ACT_PRELU) {
+                    // slopes from registers: a pointer here makes the compiler branch and load per element
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            v.v[i] = v.v[i] >= 0.f ? v.v[i] : v.v[i] * ss[t][2 * gg][i];
-                            v.v[4 + i] = v.v[4 + i] >= 0.f ? v.v[4 + i] : v.v[4 + i] * ss[t][2 * gg + 1][i];
-                        }
-                    } else if constexpr (ACT == FR_ACT_HSWISH) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v.v[j] = v.v[j] * fminf(fmaxf(v.v[j] + 3.f, 0.f), 6.f) * (1.f / 6.f);
-                    } else {
-                        act8(v, x.act_e, sel ? sel + c : nullptr);
+                    for (int i = 0; i < 4; ++i) {
+                        v.v[i] = v.v[i] >= 0.f ? v.v[i] : v.v[i] * ss[t][2 * gg][i];
+                        v.v[4 + i] = v.v[4 + i] >= 0.f ? v.v[4 + i] : v.v[4 + i] * ss[t][2 * gg + 1][i];
                     }
+                } else if constexpr (ACT == FR_ACT_HSWISH) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v.v[j] = v.v[j] * fminf(fmaxf(v.v[j] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                } else {
+                    act8(v, x.act_e, sel ? sel + c : nullptr);
+                }
+                const bool live = pix < npin && (t < NTE - 1 || c < a.C);
+                if constexpr (F32) {
+                    f32x4 r0, r1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { r0[i] = (!MASK || inimg) ? v.v[i] : 0.f; r1[i] = (!MASK || inimg) ? v.v[4 + i] : 0.f; }
+                    if (live) {
+                        *reinterpret_cast<f32x4*>(dst + (4 * t + gg) * 32) = r0;
+                        *reinterpret_cast<f32x4*>(dst + (4 * t + gg) * 32 + 16) = r1;
+                    }
+                } else {
+                    u32x4 r;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) r[i] = pack2bf(v.v[2 * i], v.v[2 * i + 1]);
-                }
-                if constexpr (MASK) {
+                    if constexpr (MASK) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) r[i] = inimg ? r[i] : 0u;
+                        for (int i = 0; i < 4; ++i) r[i] = inimg ? r[i] : 0u;
+                    }
+                    if (live) *reinterpret_cast<u32x4*>(dst + (4 * t + gg) * 16) = r;
                 }
-                if (pix < npin && (t < NTE - 1 || c < a.C)) dst[4 * t + gg] = r;
             }
         }
     }
 }
 
-template <int K, int S, int KSE, int NTE>
+template <typename T, int K, int S, int KSE, int NTE>
 __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     constexpr bool EXPAND = KSE > 0;      // KSE, NTE: k-steps and 32-channel tiles of the expand conv (compile time)
+    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr int NS = F32 ? 2 : 1;
+    constexpr int UPE = sizeof(V8<T>) / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typedef bf16 T;
     constexpr int SW = dw_sw<S>();
     const DwArgs& a = x.dw;
     const int CBV = a.CBV;
@@ -478,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
     // 1x1 weights: 1-KiB fragments by LDS-DMA (waited for inside dw_stage together with the tile)
-    for (int f = wave; f < x.NT * x.KS; f += 4)
+    for (int f = wave; f < x.NT * x.KS * NS; f += 4)
         __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)(reinterpret_cast<const u32x4*>(x.wp) + f * 64 + lane),
                                          (dw_lds_ptr_t)(smem + x.off_wp + f * 1024), 16, 0, 0);
     // bias and slopes of the 1x1 conv go to LDS as well: read from global memory in the epilogue they cost a
@@ -499,25 +529,26 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
         dw_stage<T, K, S>(a, g, smem, n, 0, ty, tx);
     } else {
         // ---- expand 1x1 conv computed here: stage the (4x narrower) block input instead of the expanded
-        // tile, multiply it on MFMA and write the activated bf16 result in the depthwise tile layout;
+        // tile, multiply it on MFMA and write the activated result in the depthwise tile layout;
         // pixels outside the image are zero (the padding of the depthwise conv), not act(bias)
         const int cin8 = x.Cin >> 3, npin = g.IH * IW;
         const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;
-        const unsigned char* Xn = reinterpret_cast<const unsigned char*>(x.xin) + (size_t)n * a.H * a.W * x.Cin * 2;
+        const unsigned char* Xn = reinterpret_cast<const unsigned char*>(x.xin) + (size_t)n * a.H * a.W * x.Cin * sizeof(T);
         const unsigned char* Z = reinterpret_cast<const unsigned char*>(a.zeros);
-        const int nin = npin * cin8;
+        const int nin = npin * cin8 * UPE;              // 16-byte units
         for (int u0 = wave * 64; u0 < nin; u0 += 256) {
             const int u = u0 + lane;
             if (u < nin) {
-                const unsigned pix = div32(u, x.d_cin8), cv = u - pix * cin8;
+                const unsigned q = (unsigned)u / UPE;
+                const unsigned pix = div32(q, x.d_cin8), cv = q - pix * cin8;
                 const unsigned iy = div32(pix, g.d_iw), ix = pix - iy * IW;
                 const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
                 const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-                const unsigned char* src = ok ? Xn + ((gy * a.W + gx) * x.Cin + (int)cv * 8) * 2 : Z;
+                const unsigned char* src = ok ? Xn + ((gy * a.W + gx) * x.Cin + (int)cv * 8) * (int)sizeof(T) + (u % UPE) * 16 : Z;
                 __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + x.off_in + u0 * 16), 16, 0, 0);
             }
         }
-        for (int f = wave; f < NTE * KSE; f += 4)
+        for (int f = wave; f < NTE * KSE * NS; f += 4)
             __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)(reinterpret_cast<const u32x4*>(x.we) + f * 64 + lane),
                                              (dw_lds_ptr_t)(smem + x.off_we + f * 1024), 16, 0, 0);
         // expand bias and slopes: [NTe*32] floats each, behind the staged input
@@ -533,22 +564,22 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
         dw_stage<T, K, S, false>(a, g, smem, n, 0, ty, tx);               // taps + bias; waits for everything
         const bool border = gy0 < 0 || gx0 < 0 || gy0 + g.IH > a.H || gx0 + IW > a.W;
         if (x.act_e == FR_ACT_RELU) {
-            if (border) dwp_expand<KSE, NTE, FR_ACT_RELU, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
-            else dwp_expand<KSE, NTE, FR_ACT_RELU, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            if (border) dwp_expand<T, KSE, NTE, FR_ACT_RELU, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            else dwp_expand<T, KSE, NTE, FR_ACT_RELU, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
         } else if (x.act_e == FR_ACT_PRELU && sel) {
-            if (border) dwp_expand<KSE, NTE, FR_ACT_PRELU, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
-            else dwp_expand<KSE, NTE, FR_ACT_PRELU, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            if (border) dwp_expand<T, KSE, NTE, FR_ACT_PRELU, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            else dwp_expand<T, KSE, NTE, FR_ACT_PRELU, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
         } else if (x.act_e == FR_ACT_HSWISH) {
-            if (border) dwp_expand<KSE, NTE, FR_ACT_HSWISH, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
-            else dwp_expand<KSE, NTE, FR_ACT_HSWISH, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            if (border) dwp_expand<T, KSE, NTE, FR_ACT_HSWISH, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            else dwp_expand<T, KSE, NTE, FR_ACT_HSWISH, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
         } else {
-            dwp_expand<KSE, NTE, -1, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            dwp_expand<T, KSE, NTE, -1, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
         }
         __syncthreads();
     }
 
-    // depthwise into registers (two passes at most), as bf16
-    u32x4 keep[2][SW];
+    // depthwise into registers (two passes at most): bf16, or bf16 hi + lo of the fp32 result
+    u32x4 keep[2][SW][NS];
     unsigned kpx[2], kcv[2];
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
@@ -560,9 +591,17 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
             Vec8f out[SW];
             dw_item<T, K, S>(a, tile, wl, bl, IW, g.PP, cv, oy, sx, out);
 #pragma unroll
-            for (int o = 0; o < SW; ++o)
+            for (int o = 0; o < SW; ++o) {
+                if constexpr (F32) {
+                    bf16x8 hi, lo;
+                    split8(out[o], hi, lo);
+                    keep[ps][o][0] = __builtin_bit_cast(u32x4, hi);
+                    keep[ps][o][1] = __builtin_bit_cast(u32x4, lo);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) keep[ps][o][i] = pack2bf(out[o].v[2 * i], out[o].v[2 * i + 1]);
+                    for (int i = 0; i < 4; ++i) keep[ps][o][0][i] = pack2bf(out[o].v[2 * i], out[o].v[2 * i + 1]);
+                }
+            }
             kpx[ps] = oy * a.TW + sx * SW;
             kcv[ps] = cv;
         }
@@ -573,14 +612,16 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
         if (kpx[ps] != 0xffffffffu) {
 #pragma unroll
             for (int o = 0; o < SW; ++o)
-                *reinterpret_cast<u32x4*>(smem + (kpx[ps] + o) * x.pitch + kcv[ps] * 16) = keep[ps][o];
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp)
+                    *reinterpret_cast<u32x4*>(smem + sp * x.off_lo + (kpx[ps] + o) * x.pitch + kcv[ps] * 16) = keep[ps][o][sp];
         }
     __syncthreads();
 
     // 1x1 conv on MFMA: D[cout][pixel] = W . dwo^T, 32 pixels per wave step
     const int p = lane & 31, h = lane >> 5;
     constexpr int SG = 2;
-    constexpr int PITCH = stage_pitch(SG * 64);
+    constexpr int PITCH = stage_pitch(SG * 32 * (int)sizeof(T));
     unsigned char* stage = smem + x.off_stage + wave * 32 * PITCH;
     const bf16x8* wf = reinterpret_cast<const bf16x8*>(smem + x.off_wp) + lane;
     EpiArgs e2 = x.e;
@@ -604,18 +645,26 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                     // run-time k loop (no guarded 8-step unroll: the early blocks have 1..5 steps and the kernel is
                     // bound by instruction issue); the half-step beyond C of the last step reads zeros
-                    const bf16x8* wt = wf + t * x.KS * 64;
+                    const bf16x8* wt = wf + t * x.KS * NS * 64;
 #pragma unroll 1
                     for (int s = 0; s < x.KS; ++s) {
                         bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow + 32 * s);
-                        if (16 * s + 8 * h >= a.C) xf = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[s * 64], xf, acc, 0, 0, 0);
+                        const bool dead = 16 * s + 8 * h >= a.C;
+                        if (dead) xf = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[s * NS * 64], xf, acc, 0, 0, 0);
+                        if constexpr (F32) {
+                            bf16x8 xl = *reinterpret_cast<const bf16x8*>(xrow + x.off_lo + 32 * s);
+                            if (dead) xl = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[s * NS * 64], xl, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[(s * NS + 1) * 64], xf, acc, 0, 0, 0);
+                        }
                     }
-                    epilogue_stage(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, p, 32 * tt + 16 * h);
+                    if constexpr (F32) epilogue_stage_f32(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, p, 32 * tt + 16 * h);
+                    else epilogue_stage(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, p, 32 * tt + 16 * h);
                 }
             }
             // write the staged [32 pixels][<= 64 channels] back: consecutive pixels of a tile row are contiguous
-            const int ncol = min(SG * 32, cout - tg * 32), cr = ncol >> 3;
+            const int ncol = min(SG * 32, cout - tg * 32), cr = (ncol * (int)sizeof(T)) >> 4;
             const unsigned magic = (65536u + cr - 1) / cr;
             __builtin_amdgcn_wave_barrier();
             for (int c = lane; c < 32 * cr; c += 64) {
@@ -625,7 +674,8 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
                 const int y = oy0 + (int)qy, xx = ox0 + (int)qx;
                 if (qpx < x.npx && y < a.Ho && xx < a.Wo) {
                     const u32x4 v = *reinterpret_cast<const u32x4*>(stage + q * PITCH + ch * 16);
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(x.e.y) + (((long)n * a.Ho + y) * a.Wo + xx) * cout + tg * 32 + ch * 8) = v;
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(x.e.y) +
+                                              ((((long)n * a.Ho + y) * a.Wo + xx) * cout + tg * 32) * (long)sizeof(T) + ch * 16) = v;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -633,76 +683,115 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     }
 }
 
-struct DwpPlan { int TH, TW; size_t lds; int off_wp, off_stage, npx_pad, pitch, off_we, off_in, off_pb; };
+struct DwpPlan { int TH, TW; size_t lds; int off_wp, off_stage, npx_pad, pitch, off_we, off_in, off_pb, off_lo; };
 
-// Tile for the fused form: all channels in one block, <= 512 work items, everything within 64 KB of LDS.
-// cin > 0: the expand 1x1 conv (cin -> C) is computed in the kernel too.
+// Tile for the fused form: all channels in one block, <= 512 work items, everything within 64 KB of LDS
+// (80 KB for fp32 plans: two blocks per CU).  cin > 0: the expand 1x1 conv (cin -> C) is computed in the kernel too.
 // Measured-best tiles of the fused kernels (see kDwTiles above; tools/dwp_probe.py).
 struct DwpTileEntry { int C, cin, Ho, k, s, cout, TH, TW; };
 static const DwpTileEntry kDwpTiles[] = {
 #include "dwp_tiles.inc"
 };
 
-static bool dwp_pick(int k, int s, int C, int Ho, int Wo, int cout, int cin, DwpPlan* out) {
+// fp32 plans (tools/dwp_probe.py <model> 512 f32; gpurun_out/dwp_probe_b512_*_f32.txt): LDS holds half as many pixels,
+// so the winners are small tiles; shapes not listed use the cost model
+static const DwpTileEntry kDwpTilesF32[] = {
+    {16, 0, 56, 3, 2, 32, 14, 8}, {32, 0, 28, 3, 2, 64, 4, 28}, {32, 0, 112, 3, 1, 16, 16, 16}, {16, 0, 112, 3, 1, 16, 16, 28},
+    {96, 16, 56, 3, 2, 24, 2, 8}, {64, 16, 56, 3, 2, 24, 4, 8}, {72, 24, 56, 3, 1, 24, 8, 4}, {72, 16, 28, 3, 2, 24, 7, 4},
+    {88, 24, 28, 3, 1, 24, 8, 4},
+};
+
+static bool dwp_pick(bool f32, int k, int s, int C, int Ho, int Wo, int cout, int cin, DwpPlan* out) {
     const int CV = C / 8, sw = s == 2 ? 2 : 4;
+    const int ns = f32 ? 2 : 1, es = f32 ? 4 : 2;
     if (C % 8 || CV > 16 || C > 128 || cout % 8 || cout > 128 || (k != 3 && k != 5) || (s != 1 && s != 2)) return false;
+    // fp32 plans without the expand conv: measured per shape on mobilenetv1 / v3 (512-image launches), the fused form wins
+    // for 16..32 channels (0.146 vs 0.170 ms, 0.130 vs 0.178, 0.079 vs 0.094, 0.34 vs 0.43) and loses for 8 channels
+    // (0.269 vs 0.242) and from 64 channels up (0.104 vs 0.092, 0.083 vs 0.055): the hi + lo planes leave too few pixels per tile
+    if (f32 && !cin && (C < 16 || C > 32)) return false;
+    // bf16 plans, same measurement (mobilenetv1): wins for 16..64 channels (0.066 vs 0.078 ms, 0.067 vs 0.086, 0.039 vs 0.051,
+    // 0.054 vs 0.057), loses for 8 (0.146 vs 0.132) and badly for 128 channels on the 14x14 maps (0.076 vs 0.039 per layer)
+    if (!f32 && !cin && (C < 16 || C > 64)) return false;
     if (cin) {        // expand form: 3x3 only, and only the (k-steps, channel tiles) shapes that are instantiated
         const int kse = cdiv(cin, 16), nte = cdiv(C, 32);
         if (cin % 8 || k != 3 || !((kse == 1 && (nte == 2 || nte == 3)) || (kse == 2 && nte == 3))) return false;
     }
     const int KS = cdiv(C, 16), NT = cdiv(cout, 32);
     const int KSe = cdiv(cin, 16), NTe = cdiv(C, 32);
-    // row pitch of the LDS depthwise result: an odd number of 16-byte slots keeps the b128 fragment reads of
-    // 8 consecutive rows on distinct bank groups
+    // row pitch of the LDS depthwise result (one bf16 plane): an odd number of 16-byte slots keeps the b128
+    // fragment reads of 8 consecutive rows on distinct bank groups
     const int pitch = C * 2 + ((CV & 1) ? 32 : 16);
+    const size_t cap = f32 ? 80 * 1024 : 64 * 1024;
     double best = 1e30; bool found = false;
-    const int ths[] = {4, 7, 8, 14, 16};
+    const int ths[] = {2, 4, 7, 8, 14, 16};
     const int tws[] = {4, 8, 16, 28, 32, 56};
     int fth = 0, ftw = 0;                                 // tuning override: FR_DWP_TILE="C,cin,TH,TW" for the matching layers
     if (const char* ov = getenv("FR_DWP_TILE")) { int c0, ci; if (sscanf(ov, "%d,%d,%d,%d", &c0, &ci, &fth, &ftw) != 4 || c0 != C || ci != cin) fth = ftw = 0; }
-    if (!fth && Ho == Wo)
+    if (!fth && Ho == Wo && !f32)
         for (const DwpTileEntry& e : kDwpTiles)
+            if (e.C == C && e.cin == cin && e.Ho == Ho && e.k == k && e.s == s && e.cout == cout) { fth = e.TH; ftw = e.TW; break; }
+    if (!fth && Ho == Wo && f32)
+        for (const DwpTileEntry& e : kDwpTilesF32)
             if (e.C == C && e.cin == cin && e.Ho == Ho && e.k == k && e.s == s && e.cout == cout) { fth = e.TH; ftw = e.TW; break; }
     for (int th : ths) for (int tw : tws) {
         if (fth && (th != fth || tw != ftw)) continue;
+        if (th == 2 && !f32) continue;                    // (2-row tiles: fp32 plans only, where LDS is the limit)
         if (th - Ho >= 2 || tw - Wo >= 4) continue;
         const int items = th * (tw / sw) * CV;
         if (items > 512) continue;
         const int npx_pad = cdiv(th * tw, 32) * 32;
-        const size_t dwo = (size_t)npx_pad * pitch;
+        const size_t plane = (size_t)npx_pad * pitch, dwo = plane * ns;
         const double IH = (th - 1) * s + k, IW = (tw - 1) * s + k;
-        // tile + taps + bias; a tile computed in the kernel has one spare 16-byte slot per pixel, so that the
+        // tile + taps + bias; a tile computed in the kernel has one spare vector slot per pixel, so that the
         // MFMA lanes (one pixel each) write it without bank conflicts
-        const size_t tile = dw_lds_bytes(false, k, s, th, tw, CV) + (cin ? (size_t)(IH * IW) * 16 : 0);
+        const size_t tile = dw_lds_bytes(f32, k, s, th, tw, CV) + (cin ? (size_t)(IH * IW) * (f32 ? 32 : 16) : 0);
         // the output staging tiles live behind the depthwise result, inside the (by then dead) input tile
         const size_t off_stage = align_up(dwo, 16);
-        const size_t off_wp = align_up(std::max(tile, off_stage + 4 * 32 * (size_t)stage_pitch(2 * 64)), 1024);
-        const size_t off_pb = off_wp + (size_t)NT * KS * 1024;
+        const size_t off_wp = align_up(std::max(tile, off_stage + 4 * 32 * (size_t)stage_pitch(2 * 32 * es)), 1024);
+        const size_t off_pb = off_wp + (size_t)NT * KS * ns * 1024;
         const size_t off_we = off_pb + (size_t)NT * 256;
-        const size_t off_in = off_we + (size_t)NTe * KSe * 1024;
-        const size_t lds = off_in + (cin ? align_up((size_t)(IH * IW) * cin * 2, 16) + (size_t)NTe * 256 : 0);
-        if (lds > 64 * 1024) continue;
+        const size_t off_in = off_we + (size_t)NTe * KSe * ns * 1024;
+        const size_t lds = off_in + (cin ? align_up((size_t)(IH * IW) * cin * es, 16) + (size_t)NTe * 256 : 0);
+        if (lds > cap) continue;
         const double useful = (double)std::min(th, Ho) * std::min(tw, Wo);
         // staged input per useful output, padded MFMA rows, and a preference for >= 3 blocks per CU
         double cost = (IH * IW) / useful + 0.5 * npx_pad / useful + (lds > 53 * 1024 ? 0.4 : lds > 40 * 1024 ? 0.2 : 0.0) + (items < 192 ? 0.5 : 0.0);
         cost *= (double)cdiv(Ho, th) * th * cdiv(Wo, tw) * tw / ((double)Ho * Wo);   // edge waste
         if (cost < best) {
             best = cost; found = true;
-            *out = DwpPlan{th, tw, lds, (int)off_wp, (int)off_stage, npx_pad, pitch, (int)off_we, (int)off_in, (int)off_pb};
+            *out = DwpPlan{th, tw, lds, (int)off_wp, (int)off_stage, npx_pad, pitch, (int)off_we, (int)off_in, (int)off_pb, (int)plane};
         }
     }
     return found;
 }
 
-bool dwp_supported(int k, int stride, int C, int Ho, int Wo, int cout, int cin) {
+bool dwp_supported(bool f32, int k, int stride, int C, int Ho, int Wo, int cout, int cin) {
     DwpPlan pl;
-    return dwp_pick(k, stride, C, Ho, Wo, cout, cin, &pl);
+    return dwp_pick(f32, k, stride, C, Ho, Wo, cout, cin, &pl);
 }
 
-int launch_dwp(int k, int stride, DwArgs a, const bf16* wp, const EpiArgs& e, const DwpExpand* ex, hipStream_t st) {
+template <typename T>
+static int launch_dwp_t(int k, int stride, const DwpArgs& x, const DwGeom& g, const DwpPlan& pl, bool ex, dim3 grid, hipStream_t st) {
+#define FR_DWP_GO(KK, SS, KE, NE) do { auto kern = dwp_kernel<T, KK, SS, KE, NE>; \
+        if (pl.lds > 65536) FR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds)); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, st, x, g); } while (0)
+#define FR_DWP_CASE(KK, SS) if (!ex && k == KK && stride == SS) FR_DWP_GO(KK, SS, 0, 0);
+#define FR_DWX_CASE(SS, KE, NE) if (ex && k == 3 && stride == SS && x.KSe == KE && x.NTe == NE) FR_DWP_GO(3, SS, KE, NE);
+    FR_DWP_CASE(3, 1) else FR_DWP_CASE(3, 2) else FR_DWP_CASE(5, 1) else FR_DWP_CASE(5, 2)
+    else FR_DWX_CASE(1, 1, 2) else FR_DWX_CASE(2, 1, 2) else FR_DWX_CASE(1, 1, 3) else FR_DWX_CASE(2, 1, 3)
+    else FR_DWX_CASE(1, 2, 3) else FR_DWX_CASE(2, 2, 3)
+    else FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: no kernel for this shape");
+#undef FR_DWP_CASE
+#undef FR_DWX_CASE
+#undef FR_DWP_GO
+    FR_LAUNCH_CHECK("dwp_kernel");
+    return FR_OK;
+}
+
+int launch_dwp(bool f32, int k, int stride, DwArgs a, const bf16* wp, const EpiArgs& e, const DwpExpand* ex, hipStream_t st) {
     DwpPlan pl;
     const int cin = ex ? ex->Cin : 0;
-    if (!a.zeros || a.N <= 0 || !dwp_pick(k, stride, a.C, a.Ho, a.Wo, e.cout, cin, &pl)) FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: shape not supported");
+    if (!a.zeros || a.N <= 0 || !dwp_pick(f32, k, stride, a.C, a.Ho, a.Wo, e.cout, cin, &pl)) FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: shape not supported");
     if ((long)a.H * a.W * a.C * 4 >= 0x7FFFFFFFL) FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: image above 2 GB");
     a.TH = pl.TH; a.TW = pl.TW; a.CBV = a.C / 8; a.cchunks = 1;
     a.tiles_y = cdiv(a.Ho, a.TH); a.tiles_x = cdiv(a.Wo, a.TW);
@@ -713,12 +802,13 @@ int launch_dwp(int k, int stride, DwArgs a, const bf16* wp, const EpiArgs& e, co
     g.IH = (a.TH - 1) * stride + k; g.IW = (a.TW - 1) * stride + k;
     g.nstrips = a.TW / sw;
     g.nitems = a.TH * g.nstrips * a.CBV;
-    g.nunits = g.IH * g.IW * a.CBV;
+    g.nunits = g.IH * g.IW * a.CBV * (f32 ? 2 : 1);
     g.PP = ex ? a.CBV + 1 : a.CBV;
     g.d_cbv = make_div32(a.CBV); g.d_iw = make_div32(g.IW); g.d_ns = make_div32(g.nstrips); g.d_tw = make_div32(a.TW);
     DwpArgs x{};
     x.dw = a; x.wp = wp; x.e = e; x.KS = cdiv(a.C, 16); x.NT = cdiv(e.cout, 32);
-    x.npx = a.TH * a.TW; x.npx_pad = pl.npx_pad; x.pitch = pl.pitch; x.off_wp = pl.off_wp; x.off_stage = pl.off_stage; x.off_pb = pl.off_pb;
+    x.npx = a.TH * a.TW; x.npx_pad = pl.npx_pad; x.pitch = pl.pitch; x.off_lo = pl.off_lo;
+    x.off_wp = pl.off_wp; x.off_stage = pl.off_stage; x.off_pb = pl.off_pb;
     if (ex) {
         x.xin = ex->xin; x.we = ex->we; x.be = ex->bias; x.se = ex->slope; x.act_e = ex->act; x.Cin = ex->Cin;
         x.KSe = cdiv(ex->Cin, 16); x.NTe = cdiv(a.C, 32); x.off_we = pl.off_we; x.off_in = pl.off_in;
@@ -728,16 +818,9 @@ int launch_dwp(int k, int stride, DwArgs a, const bf16* wp, const EpiArgs& e, co
         g.n0 = n0;
         dim3 grid((unsigned)a.tiles_x, (unsigned)a.tiles_y, (unsigned)std::min(65535, a.N - n0));
         dw_block_geom(g, (int)grid.x, (int)grid.y, (int)grid.z);
-#define FR_DWP_CASE(KK, SS) if (!ex && k == KK && stride == SS) hipLaunchKernelGGL((dwp_kernel<KK, SS, 0, 0>), grid, dim3(256), pl.lds, st, x, g);
-#define FR_DWX_CASE(SS, KE, NE) if (ex && k == 3 && stride == SS && x.KSe == KE && x.NTe == NE) \
-        hipLaunchKernelGGL((dwp_kernel<3, SS, KE, NE>), grid, dim3(256), pl.lds, st, x, g);
-        FR_DWP_CASE(3, 1) else FR_DWP_CASE(3, 2) else FR_DWP_CASE(5, 1) else FR_DWP_CASE(5, 2)
-        else FR_DWX_CASE(1, 1, 2) else FR_DWX_CASE(2, 1, 2) else FR_DWX_CASE(1, 1, 3) else FR_DWX_CASE(2, 1, 3)
-        else FR_DWX_CASE(1, 2, 3) else FR_DWX_CASE(2, 2, 3)
-        else FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: no kernel for this shape");
-#undef FR_DWP_CASE
-#undef FR_DWX_CASE
-        FR_LAUNCH_CHECK("dwp_kernel");
+        const int rc = f32 ? launch_dwp_t<float>(k, stride, x, g, pl, ex != nullptr, grid, st)
+                           : launch_dwp_t<bf16>(k, stride, x, g, pl, ex != nullptr, grid, st);
+        if (rc) return rc;
     }
     return FR_OK;
 }

@@ -39,17 +39,17 @@ struct DwArgs {
     float* pool;          // optional [N][pool_tiles][C] per-tile channel sums of the OUTPUT (squeeze-excite pooling), or NULL
     int pool_tiles;       // tiles per image the caller sized `pool` for (must equal dw_tiles_per_image)
 };
-// Depthwise + the following 1x1 conv in one kernel (bf16; all channels of a tile in one block).
+// Depthwise + the following 1x1 conv in one kernel (bf16 or fp32 plans; all channels of a tile in one block).
 // Optionally the expand 1x1 conv in front of the depthwise conv is computed in the same kernel too.
 struct DwpExpand {
-    const bf16* xin;      // block input [N,H,W,Cin] (H,W = the depthwise input size)
-    const bf16* we;       // expand weights packed [NT][KS][64][8]
+    const void* xin;      // block input [N,H,W,Cin] (H,W = the depthwise input size), bf16 or fp32 as the plan stores it
+    const bf16* we;       // expand weights packed [NT][KS][NS][64][8]
     const float* bias;    // padded to a multiple of 32
     const float* slope;   // PReLU slopes or NULL
     int act, Cin;
 };
-bool dwp_supported(int k, int stride, int C, int Ho, int Wo, int cout, int cin /* 0: no expand */);
-int launch_dwp(int k, int stride, DwArgs a, const bf16* w_pw_packed, const EpiArgs& pw_epilogue, const DwpExpand* expand, hipStream_t st);
+bool dwp_supported(bool f32, int k, int stride, int C, int Ho, int Wo, int cout, int cin /* 0: no expand */);
+int launch_dwp(bool f32, int k, int stride, DwArgs a, const bf16* w_pw_packed, const EpiArgs& pw_epilogue, const DwpExpand* expand, hipStream_t st);
 // Spatial tiles per image launch_dw will use for this layer shape (sizes DwArgs::pool).
 int dw_tiles_per_image(bool f32, int k, int stride, int C, int Ho, int Wo);
 int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st);

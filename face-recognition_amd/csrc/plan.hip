@@ -373,31 +373,33 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         if (L.src < 0 && L.kind != K_STEM) { need_input_copy = true; input_last_use = i; }
     }
     last_use[n - 1] = n;   // final output stays live
-    // depthwise -> 1x1 fusion (bf16, C <= 128): the depthwise output stays in LDS (k_dw.hip, dwp_kernel).
+    // depthwise -> 1x1 fusion (C <= 128): the depthwise output stays in LDS (k_dw.hip, dwp_kernel).
     for (int i = 0; !no_fuse && i + 1 < n; ++i) {
         Layer& D = pl->layers[i];
         Layer& P = pl->layers[i + 1];
-        if (D.kind == K_DW && !D.in_f32 && P.kind == K_PW && P.src == i && last_use[i] == i + 1 && !P.out_f32 &&
-            dwp_supported(D.k, D.stride, D.C, D.H, D.W, P.cout, 0)) {
-            D.fused_next = true;
-            P.fuse_src = i;
-            const int e_last_use = D.src >= 0 ? last_use[D.src] : -1;      // before the fused kernel extends it
-            if (D.src >= 0) last_use[D.src] = std::max(last_use[D.src], i + 1);
+        const bool af = pl->act_f32();
+        if (!(D.kind == K_DW && D.in_f32 == af && P.kind == K_PW && P.src == i && last_use[i] == i + 1 && P.out_f32 == af)) continue;
+        // the expand 1x1 conv in front of the depthwise conv as well (expand -> depthwise -> project in one
+        // launch, the 4x wider expanded activation never leaves LDS); FR_FUSE3=0 keeps the expand conv separate
+        const bool fuse3 = !(getenv("FR_FUSE3") && atoi(getenv("FR_FUSE3")) == 0);
+        bool with_expand = false;
+        if (fuse3 && D.src >= 0 && D.src == i - 1) {
+            const Layer& E = pl->layers[i - 1];
+            const bool se_in = E.src >= 0 && pl->layers[E.src].kind == K_SE;
+            with_expand = E.kind == K_PW && E.in_f32 == af && E.out_f32 == af && E.residual < 0 && !se_in && last_use[i - 1] == i &&
+                          E.fuse_src < 0 && dwp_supported(af, D.k, D.stride, D.C, D.H, D.W, P.cout, E.K);
+        }
+        if (!with_expand && !dwp_supported(af, D.k, D.stride, D.C, D.H, D.W, P.cout, 0)) continue;
+        D.fused_next = true;
+        P.fuse_src = i;
+        if (D.src >= 0) last_use[D.src] = std::max(last_use[D.src], i + 1);
+        else if (need_input_copy) input_last_use = std::max(input_last_use, i + 1);
+        if (with_expand) {
+            Layer& E = pl->layers[i - 1];
+            E.fused_next = true;
+            P.fuse_src2 = i - 1;
+            if (E.src >= 0) last_use[E.src] = std::max(last_use[E.src], i + 1);
             else if (need_input_copy) input_last_use = std::max(input_last_use, i + 1);
-            // the expand 1x1 conv in front of the depthwise conv as well (expand -> depthwise -> project in one
-            // launch, the 4x wider expanded activation never leaves LDS); FR_FUSE3=0 keeps the expand conv separate
-            const bool fuse3 = !(getenv("FR_FUSE3") && atoi(getenv("FR_FUSE3")) == 0);
-            if (fuse3 && D.src >= 0 && D.src == i - 1) {
-                Layer& E = pl->layers[i - 1];
-                const bool se_in = E.src >= 0 && pl->layers[E.src].kind == K_SE;
-                if (E.kind == K_PW && !E.in_f32 && !E.out_f32 && E.residual < 0 && !se_in && e_last_use == i && E.fuse_src < 0 &&
-                    dwp_supported(D.k, D.stride, D.C, D.H, D.W, P.cout, E.K)) {
-                    E.fused_next = true;
-                    P.fuse_src2 = i - 1;
-                    if (E.src >= 0) last_use[E.src] = std::max(last_use[E.src], i + 1);
-                    else if (need_input_copy) input_last_use = std::max(input_last_use, i + 1);
-                }
-            }
         }
     }
     std::vector<size_t>& sizes = pl->slot_bytes;
@@ -555,10 +557,10 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
                     DwpExpand ex{};
                     if (L.fuse_src2 >= 0) {
                         const Layer& E = plan->layers[L.fuse_src2];
-                        ex.xin = reinterpret_cast<const bf16*>(E.src < 0 ? in_nhwc : (const void*)base[plan->layers[E.src].slot]);
+                        ex.xin = E.src < 0 ? in_nhwc : (const void*)base[plan->layers[E.src].slot];
                         ex.we = E.w_packed; ex.bias = E.bias; ex.slope = E.slope; ex.act = E.act; ex.Cin = E.K;
                     }
-                    rc = launch_dwp(D.k, D.stride, a, L.w_packed, EpiArgs{L.bias, L.slope, res, y, L.cout, L.act},
+                    rc = launch_dwp(af32, D.k, D.stride, a, L.w_packed, EpiArgs{L.bias, L.slope, res, y, L.cout, L.act},
                                     L.fuse_src2 >= 0 ? &ex : nullptr, st);
                     break;
                 }

@@ -1,5 +1,5 @@
 """Sweep tiles (TH, TW) of the fused depthwise+1x1 kernels per layer shape via the FR_DWP_TILE override and print
-the best few.  Usage (GPU): python tools/dwp_probe.py <model> <batch>"""
+the best few.  Usage (GPU): python tools/dwp_probe.py <model> <batch> [bf16|f32]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,7 @@ batch = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = fr.get_network(model_name).to(dev).eval()
-model.precision = "bf16"
+model.precision = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 x = (torch.rand((batch, 3, 112, 112)) * 2 - 1).to(dev)
 plan = model.plan(dev)
 g = fr.models._Graph(); model.lower(g)
@@ -34,7 +34,7 @@ for i, r in enumerate(rows):
     shapes.setdefault((c, cin, ho, int(g.descs[dwi].kernel), int(g.descs[dwi].stride), plan.dims[i][0]), []).append(i)
 for (c, cin, ho, k, s, cout), idx in shapes.items():
     res = []
-    for th in (4, 7, 8, 14, 16):
+    for th in (2, 4, 7, 8, 14, 16):
         for tw in (4, 8, 16, 28, 32, 56):
             os.environ["FR_DWP_TILE"] = f"{c},{cin},{th},{tw}"
             try:
