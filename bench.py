@@ -39,7 +39,7 @@ BASELINE_CONFIGS = {("mobilenetv3_large", 1024): "BASELINE.json configs[1]", ("s
 # When two kernel families are within 5 % of the largest time per step, the one earlier in this list is reported as
 # the dominant kernel, so that the choice does not flip on a 0.001 ms difference between runs.  Unfused kernels come
 # first: their algorithmic bytes are the bytes they really move.
-DOMINANT_PREFERENCE = ["pw_stream_kernel", "pw_gemm_kernel", "conv_halo_kernel", "dw_kernel", "pw_proj_kernel",
+DOMINANT_PREFERENCE = ["pw_stream_kernel", "pw_gemm_kernel", "conv_halo16_kernel", "conv_halo_kernel", "dw_kernel", "pw_proj_kernel",
                        "conv_glds_kernel", "dwp_kernel", "stem_kernel"]
 
 

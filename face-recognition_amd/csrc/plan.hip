@@ -39,6 +39,7 @@ struct Layer {
     int K2 = 0, KS2 = 0, NT2 = 0, chunk_ks2 = 0;   // SE fc2 geometry
     int conv_bk = 32;                     // K-slice width the conv weights were packed with
     bool conv_halo = false;               // dense 3x3 stride 1: conv_halo_kernel (FR_CONV_HALO, read when the plan is created)
+    bool conv_halo16 = false;             // ... in its 16x16x32 MFMA form (weights packed in that kernel's row order)
     bool via_conv = false;                // Linear routed through the conv implicit-GEMM kernel
     bool fused_next = false;              // (reserved: a layer computed inside the next layer's kernel; none today)
     int fuse_src = -1;                    // 1x1 conv: index of the depthwise layer computed in its kernel (dwp_kernel)
@@ -128,8 +129,10 @@ void pack_gemm_weights(const std::vector<double>& W, int cout, int K, int ns, st
 }
 
 // Pack W(cout, tap, c) into the LDS image of conv_gemm_kernel: [cout tile][ks][NS][BN rows][32].
+// row16: the row order of conv_halo16_kernel (16x16x32 MFMA): row rr of a wave's 64 couts holds cout
+// 16 * ((rr % 16) / 4) + 4 * (rr / 16) + rr % 4, so that lane group kg collects couts 16 kg .. 16 kg + 15.
 template <typename F>
-void pack_conv_weights(F&& wfn, int cout, int cin, int taps, int ns, int bk, std::vector<uint16_t>& out) {
+void pack_conv_weights(F&& wfn, int cout, int cin, int taps, int ns, int bk, std::vector<uint16_t>& out, bool row16 = false) {
     const int bn = conv_block_couts(cout), ntiles = cdiv(cout, bn), chunks = cin / bk, KS = taps * chunks;
     out.assign((size_t)ntiles * KS * ns * bn * bk, 0);
     for (int nt = 0; nt < ntiles; ++nt)
@@ -139,7 +142,9 @@ void pack_conv_weights(F&& wfn, int cout, int cin, int taps, int ns, int bk, std
             // per-XCD footprint above the 4 MB L2: 74 % hit rate on the 256-channel SphereFace layers)
             const int tap = ks % taps, c0 = (ks / taps) * bk;
             for (int r = 0; r < bn; ++r) {
-                const int co = nt * bn + (r / 32) * 32 + mfma_row_to_cout(r % 32);
+                const int rr = r % 64;
+                const int co = row16 ? nt * bn + (r / 64) * 64 + 16 * ((rr % 16) / 4) + 4 * (rr / 16) + rr % 4
+                                     : nt * bn + (r / 32) * 32 + mfma_row_to_cout(r % 32);
                 if (co >= cout) continue;
                 for (int kk = 0; kk < bk; ++kk) {
                     const double w = wfn(co, tap, c0 + kk);
@@ -243,8 +248,10 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
             L.conv_bk = (!L.in_f32 && d.cin % 64 == 0 && d.cin >= bk64_min) ? 64 : 32;
             L.conv_halo = halo_on && !L.in_f32 && conv_halo_rows(3, d.stride, d.pad, L.inW, 32) > 0;
             if (L.conv_halo) L.conv_bk = 32;                  // the shared-pixel kernel walks 32-channel chunks
+            // FR_CONV_MFMA=32 keeps the shared-pixel kernel on the 32x32x16 MFMA shape (default: 16x16x32)
+            L.conv_halo16 = L.conv_halo && !af32 && !(getenv("FR_CONV_MFMA") && atoi(getenv("FR_CONV_MFMA")) == 32);
             pack_conv_weights([&](int co, int tap, int c) { return (double)d.weight[((size_t)co * cin + c) * 9 + tap] * scale[co]; },
-                              d.cout, d.cin, 9, L.in_f32 ? 2 : 1, L.conv_bk, packed);
+                              d.cout, d.cin, 9, L.in_f32 ? 2 : 1, L.conv_bk, packed, L.conv_halo16);
             int rc = upload(pl, packed, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
         } else {
             FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "conv shape with no kernel");
@@ -542,7 +549,7 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
                 a.x = xin; a.w = L.w_packed;
                 a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act};
                 a.M = (long)N * L.H * L.W; a.H = L.inH; a.W = L.inW; a.Ho = L.H; a.Wo = L.W;
-                a.Cin = L.cin; a.ksize = 3; a.stride = L.stride; a.pad = L.pad; a.zeros = plan->zeros; a.bk = L.conv_bk; a.halo = L.conv_halo;
+                a.Cin = L.cin; a.ksize = 3; a.stride = L.stride; a.pad = L.pad; a.zeros = plan->zeros; a.bk = L.conv_bk; a.halo = L.conv_halo16 ? 2 : (L.conv_halo ? 1 : 0);
                 rc = launch_conv(L.in_f32, L.out_f32, a, st);
                 break;
             }
@@ -687,7 +694,7 @@ extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char**
     } else if (L.kind == K_CONV3 && L.in_f32) {
         *name = "conv_gemm_kernel";
     } else if (L.kind == K_CONV3 && L.conv_halo) {
-        *name = "conv_halo_kernel";
+        *name = L.conv_halo16 ? "conv_halo16_kernel" : "conv_halo_kernel";
     } else if (L.kind == K_LINEAR && L.via_conv) {
         *name = L.in_f32 ? "conv_gemm_kernel" : "conv_glds_kernel";
     }
