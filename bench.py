@@ -196,6 +196,9 @@ def measure_embed(fr, model, model_name, x, precision, steps, warmup, dev, world
     prof = profile_layers(fr, model, x, precision, parts) if profile else None
     step = step_fn or (lambda t: model(t, precision=precision))
     with torch.no_grad():
+        if prof is None:
+            for _ in range(10):               # ranks that did not run the profile passes: clocks and caches warm the same way
+                step(x)                       # (untimed, in addition to the W warm-up steps: 20 short steps alone measure 8 % low)
         for _ in range(warmup):
             step(x)
         sync(dev, world)
