@@ -760,6 +760,43 @@ def test_file_entry_points_against_oracle(name, tmp_path, capsys):
     assert d2 == d
 
 
+def test_eval_lfw_from_jpeg_files_and_state_dict_path(tmp_path, golden_dir):
+    """evaluate.eval exactly as train.py / the Eval notebook call it: a directory of .jpg files in LFW layout plus
+    lfw_ann.txt, `model_path` pointing at a bare state_dict (evaluate.py:380-382), default image decoding (PIL) --
+    against the oracle's pair loop on the SAME decoded pixels.  BN-calibrated weights, so decisions are non-trivial."""
+    from PIL import Image
+    faces = osc.synthetic_faces(12, 2, seed=4321)
+    root = tmp_path / "val"
+    images = {}
+    for i in range(12):
+        (root / f"p{i}").mkdir(parents=True)
+        for j in range(2):
+            f = root / f"p{i}" / f"p{i}_{j + 1:04d}.jpg"
+            Image.fromarray(faces[i, j]).save(str(f), format="JPEG", quality=95)
+            images[str(f)] = np.asarray(Image.open(str(f)).convert("RGB"), dtype=np.uint8)      # what any reader decodes
+    lines = ["24\n"] + [f"p{i} 1 2\n" for i in range(12)] + [f"p{i} 1 p{(i + 5) % 12} 2\n" for i in range(12)] + ["p0 1 p1 7\n"]
+    (root / "lfw_ann.txt").write_text("".join(lines))
+    g = np.load(os.path.join(golden_dir, "bncal_mobilenetv3_small.npz"))
+    onet = ob.seeded("mobilenetv3_small", 0)
+    sd = onet.state_dict()
+    for i, k in enumerate(g["keys"]):
+        sd[str(k)] = torch.from_numpy(g[f"s{i}"])
+    onet.load_state_dict(sd)
+    torch.save(sd, tmp_path / "w.pth")
+    torch.manual_seed(5)
+    model = fr.get_network("mobilenetv3_small")                   # other weights: eval must load model_path over them
+    mean, preds, metrics = fr.evaluate.eval(model, model_path=str(tmp_path / "w.pth"), device=DEV, val_root=str(root),
+                                            compute_full_metrics=True)
+    omean, opreds, _ = osc.eval_pairs(onet, images, lines[1:], str(root))
+    assert preds.shape == opreds.shape == (24, 4)                 # the pair with the missing image is skipped
+    assert list(preds[:, 0]) == list(opreds[:, 0]) and list(preds[:, 1]) == list(opreds[:, 1]) and list(preds[:, 3]) == list(opreds[:, 3])
+    s, o = preds[:, 2].astype(float), opreds[:, 2].astype(float)
+    assert np.abs(s - o).max() <= 1e-3 and abs(mean - omean) <= 1e-3
+    far = np.abs(o - 0.35) > 1e-3
+    assert np.array_equal(osc.decide(s)[far], osc.decide(o)[far]) and osc.decide(o).sum() > 0
+    assert metrics["true_positives"] + metrics["false_negatives"] == 12 and 0.0 <= metrics["accuracy"] <= 1.0
+
+
 def test_file_entry_points_resize_other_sizes(tmp_path):
     """Images that are not 112x112 go through the Resize step (PIL bilinear, as torchvision does for PIL inputs;
     parity unpinned: torchvision is not importable here).  Host logic only -- the oracle side uses the same PIL call."""
