@@ -675,7 +675,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo16_kernel(ConvArgs a
 // rows of the staged pixel range (multiple of 16), or 0 when the shape does not take the shared-pixel kernel
 int conv_halo_rows(int ksize, int stride, int pad, int W, int bk) {
     if (ksize != 3 || stride != 1 || pad != 1 || bk != 32) return 0;
-    if (W < 12) return 0;      // 7x7 maps (512 channels, few pixel tiles): the per-tap kernel with 64-channel slices measured faster
+    static const int min_w = [] { const char* e = getenv("FR_CONV_HALO_MINW"); return e ? atoi(e) : 12; }();   // tuning
+    if (W < min_w) return 0;   // 7x7 maps (512 channels, few pixel tiles): the per-tap kernel with 64-channel slices measured faster
     const int rb = (128 + 2 * W + 2 + 15) / 16 * 16;
     return rb <= 576 ? rb : 0;                       // 9 taps x 4 waves x 16 rows: a ninth of the range per tap
 }

@@ -178,36 +178,43 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwArgs a, PwGrid pg) {
 // while chunk c (4 k-steps = 64 input channels) is multiplied, the LDS-DMA of weight chunk c+1
 // into the other LDS buffer and the loads of activation chunk c+1 (and its SE scales) into a
 // second register set are already in flight.  One wait + one barrier per chunk.
-constexpr int PJ_CK = 4;          // k-steps per chunk
 constexpr int PJ_NT = 5;          // n-tiles per block
-
 constexpr int PJ_IMGS = 4;        // images a 128-pixel super-tile can span (needs H*W >= 43)
-struct PjRaw { u32x4 x[PJ_CK]; };
 
-template <bool SE>
+// T = bf16: chunks of 4 k-steps (64 input channels), bf16 output staged through LDS.
+// T = float (fp32 plans, round 2): chunks of 2 k-steps with hi+lo weight fragments (the same 20 KB per buffer), fp32
+// activations split on use, three MFMA passes in pw_gemm_kernel's order (same bits), fp32 output stored directly (these
+// are the narrow outputs of the project convs: <= 160 channels, 64 contiguous bytes per lane).
+template <bool SE, typename T>
 __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
+    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr int NS = F32 ? 2 : 1;
+    constexpr int CK = F32 ? 2 : 4;                     // k-steps per chunk
+    constexpr int XU = F32 ? 2 : 1;                     // 16-byte units of one lane's 8 input channels
+    struct Raw { u32x4 x[CK][XU]; };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WBUF = PJ_NT * PJ_CK * 1024;
+    constexpr int WBUF = PJ_NT * CK * NS * 1024;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int t0 = blockIdx.y * a.ntg;
     const int nt = min(a.ntg, a.NT - t0);
-    const int nch = (a.KS + PJ_CK - 1) / PJ_CK;
+    const int nch = (a.KS + CK - 1) / CK;
     const long n_super = (a.M + 127) / 128;
-    const bf16* X = reinterpret_cast<const bf16*>(a.x);
+    const T* X = reinterpret_cast<const T*>(a.x);
     constexpr int SG = 2;
     constexpr int PITCH = stage_pitch(SG * 64);
+    constexpr int STAGE_BYTES = F32 ? 0 : 4 * 32 * PITCH;
     unsigned char* stage = smem + 2 * WBUF + (size_t)wave * 32 * PITCH;
     // SE scales of the (<= 4) images this super-tile touches: [PJ_IMGS][K] fp32, staged once per
     // super-tile (per-lane global loads of the scales would be twice the activation bytes)
-    float* sc = reinterpret_cast<float*>(smem + 2 * WBUF + 4 * 32 * PITCH);
+    float* sc = reinterpret_cast<float*>(smem + 2 * WBUF + STAGE_BYTES);
     const long n_img = a.M / a.HW;
 
     for (long st = blockIdx.x; st < n_super; st += gridDim.x) {
         const long m = st * 128 + wave * 32 + p;
         const bool m_ok = m < a.M;
         const long mc = m_ok ? m : a.M - 1;
-        const bf16* xrow = X + mc * (long)a.K;
+        const T* xrow = X + mc * (long)a.K;
         const long img0 = (st * 128) / a.HW;
         const float* srow = sc + (int)(mc / a.HW - img0) * a.K;
         if constexpr (SE) {
@@ -224,20 +231,22 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
             }
         }
 
-        auto issue = [&](int c, int buf, PjRaw& raw) {
-            const int s0 = c * PJ_CK;
-            const int ns = min(PJ_CK, a.KS - s0);
-            const int nfrag = nt * ns;
+        auto issue = [&](int c, int buf, Raw& raw) {
+            const int s0 = c * CK;
+            const int ns = min(CK, a.KS - s0);
+            const int nfrag = nt * ns * NS;
             for (int f = wave; f < nfrag; f += 4) {
-                const int t = f / ns, s = f - t * ns;
-                const u32x4* src = reinterpret_cast<const u32x4*>(a.w) + (((long)(t0 + t) * a.KS + s0 + s) * 64 + lane);
-                __builtin_amdgcn_global_load_lds((pw_glb_ptr_t)src, (pw_lds_ptr_t)(smem + buf * WBUF + (t * PJ_CK + s) * 1024), 16, 0, 0);
+                const int sp = f % NS, ts = f / NS;
+                const int t = ts / ns, s = ts - t * ns;
+                const u32x4* src = reinterpret_cast<const u32x4*>(a.w) + ((((long)(t0 + t) * a.KS + s0 + s) * NS + sp) * 64 + lane);
+                __builtin_amdgcn_global_load_lds((pw_glb_ptr_t)src, (pw_lds_ptr_t)(smem + buf * WBUF + ((t * CK + s) * NS + sp) * 1024), 16, 0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < PJ_CK; ++j) {
+            for (int j = 0; j < CK; ++j) {
                 const int kk = (s0 + j) * 16 + 8 * h;
                 const int kc = kk < a.K ? kk : 0;                       // clamped: the k-step is skipped or its weights are zero
-                raw.x[j] = *reinterpret_cast<const u32x4*>(xrow + kc);
+#pragma unroll
+                for (int u = 0; u < XU; ++u) raw.x[j][u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(xrow + kc) + 16 * u);
             }
         };
 
@@ -247,39 +256,53 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-        auto compute = [&](int c, int buf, const PjRaw& raw) {
-            const int s0 = c * PJ_CK;
-            const int ns = min(PJ_CK, a.KS - s0);
+        auto compute = [&](int c, int buf, const Raw& raw) {
+            const int s0 = c * CK;
+            const int ns = min(CK, a.KS - s0);
             const bf16x8* wb = reinterpret_cast<const bf16x8*>(smem + buf * WBUF) + lane;
 #pragma unroll
-            for (int j = 0; j < PJ_CK; ++j) {
+            for (int j = 0; j < CK; ++j) {
                 if (j < ns) {
-                    bf16x8 xf;
+                    bf16x8 xf, xl;
                     const bool live = (s0 + j) * 16 + 8 * h < a.K;
-                    if constexpr (SE) {
+                    if constexpr (SE || F32) {
                         Vec8f x;
+                        if constexpr (F32) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            x.v[2 * i] = __uint_as_float(raw.x[j][i] << 16);
-                            x.v[2 * i + 1] = __uint_as_float(raw.x[j][i] & 0xffff0000u);
+                            for (int i = 0; i < 4; ++i) { x.v[i] = __uint_as_float(raw.x[j][0][i]); x.v[4 + i] = __uint_as_float(raw.x[j][XU - 1][i]); }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                x.v[2 * i] = __uint_as_float(raw.x[j][0][i] << 16);
+                                x.v[2 * i + 1] = __uint_as_float(raw.x[j][0][i] & 0xffff0000u);
+                            }
                         }
-                        const int kc = live ? (s0 + j) * 16 + 8 * h : 0;
-                        const f32x4 sa = *reinterpret_cast<const f32x4*>(srow + kc), sb = *reinterpret_cast<const f32x4*>(srow + kc + 4);
+                        if constexpr (SE) {
+                            const int kc = live ? (s0 + j) * 16 + 8 * h : 0;
+                            const f32x4 sa = *reinterpret_cast<const f32x4*>(srow + kc), sb = *reinterpret_cast<const f32x4*>(srow + kc + 4);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { x.v[i] *= sa[i]; x.v[4 + i] *= sb[i]; }
-                        xf = to_frag(x);
+                            for (int i = 0; i < 4; ++i) { x.v[i] *= sa[i]; x.v[4 + i] *= sb[i]; }
+                        }
+                        if constexpr (F32) split8(x, xf, xl); else xf = to_frag(x);
                     } else {
-                        xf = __builtin_bit_cast(bf16x8, raw.x[j]);
+                        xf = __builtin_bit_cast(bf16x8, raw.x[j][0]);
                     }
-                    if (!live) xf = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (!live) { xf = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xl = xf; }
 #pragma unroll
                     for (int t = 0; t < PJ_NT; ++t)
-                        if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[(t * PJ_CK + j) * 64], xf, acc[t], 0, 0, 0);
+                        if (t < nt) {
+                            const bf16x8 wh = wb[((t * CK + j) * NS) * 64];
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf, acc[t], 0, 0, 0);
+                            if constexpr (F32) {
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[t], 0, 0, 0);
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[((t * CK + j) * NS + 1) * 64], xf, acc[t], 0, 0, 0);
+                            }
+                        }
                 }
             }
         };
 
-        PjRaw r0, r1;
+        Raw r0, r1;
         issue(0, 0, r0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -296,31 +319,39 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
             }
         }
 
-        const long tile0 = m - p, left = a.M - tile0;
+        if constexpr (F32) {
 #pragma unroll
-        for (int tg = 0; tg < PJ_NT; tg += SG) {
-            if (tg < nt) {
+            for (int t = 0; t < PJ_NT; ++t)
+                if (t < nt) epilogue_store<float>(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok);
+        } else {
+            const long tile0 = m - p, left = a.M - tile0;
 #pragma unroll
-                for (int t = tg; t < tg + SG; ++t)
-                    if (t < PJ_NT && t < nt) epilogue_stage(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok, stage, PITCH, p, 32 * (t - tg) + 16 * h);
-                if (left > 0)
-                    stage_flush(stage, PITCH, lane, reinterpret_cast<bf16*>(a.e.y) + tile0 * a.e.cout + (t0 + tg) * 32, a.e.cout,
-                                min(SG * 32, min(a.e.cout, (t0 + nt) * 32) - (t0 + tg) * 32), left < 32 ? (int)left : 32);
+            for (int tg = 0; tg < PJ_NT; tg += SG) {
+                if (tg < nt) {
+#pragma unroll
+                    for (int t = tg; t < tg + SG; ++t)
+                        if (t < PJ_NT && t < nt) epilogue_stage(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok, stage, PITCH, p, 32 * (t - tg) + 16 * h);
+                    if (left > 0)
+                        stage_flush(stage, PITCH, lane, reinterpret_cast<bf16*>(a.e.y) + tile0 * a.e.cout + (t0 + tg) * 32, a.e.cout,
+                                    min(SG * 32, min(a.e.cout, (t0 + nt) * 32) - (t0 + tg) * 32), left < 32 ? (int)left : 32);
+                }
             }
         }
     }
 }
 
+template <typename T>
 static int launch_pw_proj(const PwArgs& a, hipStream_t st) {
+    constexpr bool F32 = std::is_same<T, float>::value;
     const long n_super = (a.M + 127) / 128;
     PwArgs b = a;
     b.ntg = PJ_NT;
     const int groups = cdiv(a.NT, b.ntg);
     dim3 grid((unsigned)std::min<long>(n_super, 4096), (unsigned)groups);
-    size_t lds = 2 * (size_t)PJ_NT * PJ_CK * 1024 + 4 * 32 * (size_t)stage_pitch(2 * 64);
+    size_t lds = 2 * (size_t)PJ_NT * (F32 ? 2 * 2 : 4) * 1024 + (F32 ? 0 : 4 * 32 * (size_t)stage_pitch(2 * 64));
     if (a.se) lds += (size_t)PJ_IMGS * a.K * 4;
-    if (a.se) { FR_BIG_LDS((pw_proj_kernel<true>), lds); hipLaunchKernelGGL((pw_proj_kernel<true>), grid, dim3(256), lds, st, b); }
-    else hipLaunchKernelGGL((pw_proj_kernel<false>), grid, dim3(256), lds, st, b);
+    if (a.se) { FR_BIG_LDS((pw_proj_kernel<true, T>), lds); hipLaunchKernelGGL((pw_proj_kernel<true, T>), grid, dim3(256), lds, st, b); }
+    else hipLaunchKernelGGL((pw_proj_kernel<false, T>), grid, dim3(256), lds, st, b);
     FR_LAUNCH_CHECK("pw_proj_kernel");
     return FR_OK;
 }
@@ -662,6 +693,7 @@ const char* pw_kernel_name(bool in_f32, bool out_f32, int K, int cout, bool se, 
     const int KS = cdiv(K, 16), NT = cdiv(cout, 32);
     int ntb, ck;
     pw_pick_tiling(in_f32, NT, KS, &ntb, &ck);
+    if (in_f32 && out_f32 && KS > 8 && (!se || HW >= 43) && !(getenv("FR_PW_F32_PROJ") && atoi(getenv("FR_PW_F32_PROJ")) == 0)) return "pw_proj_kernel";
     if (in_f32) return (out_f32 && KS <= 8 && ck >= KS) ? "pw_stream_kernel" : "pw_gemm_kernel";
     if (!out_f32 && KS > 16 && (!se || HW >= 43)) return "pw_proj_kernel";
     if (KS <= 16 && ck >= KS && (KS <= 8 || ntb <= 2)) return "pw_stream_kernel";
@@ -674,8 +706,10 @@ int launch_pw(bool in_f32, bool out_f32, const PwArgs& a, hipStream_t st) {
     int ntb, ck;
     pw_pick_tiling(in_f32, a.NT, a.KS, &ntb, &ck);
     if (ck != a.chunk_ks) FR_FAIL(FR_ERR_ARG, "pw: chunk_ks does not match pw_pick_tiling");
+    static const bool proj32 = !(getenv("FR_PW_F32_PROJ") && atoi(getenv("FR_PW_F32_PROJ")) == 0);
+    if (in_f32 && out_f32 && proj32 && a.KS > 8 && (!a.se || (a.HW >= 43 && a.M % a.HW == 0))) return launch_pw_proj<float>(a, st);
     if (in_f32 && out_f32) return launch_pw_t<float, float>(a, ntb, st);
-    if (!in_f32 && !out_f32 && a.KS > 16 && (!a.se || (a.HW >= 43 && a.M % a.HW == 0))) return launch_pw_proj(a, st);
+    if (!in_f32 && !out_f32 && a.KS > 16 && (!a.se || (a.HW >= 43 && a.M % a.HW == 0))) return launch_pw_proj<bf16>(a, st);
     if (!in_f32 && !out_f32) return launch_pw_t<bf16, bf16>(a, ntb, st);
     if (!in_f32 && out_f32) return launch_pw_t<bf16, float>(a, ntb, st);
     FR_FAIL(FR_ERR_UNSUPPORTED, "pw: fp32 input with bf16 output is not instantiated");
