@@ -78,12 +78,15 @@ FR_DEV void dw_stage(const DwArgs& a, const DwGeom& g, unsigned char* smem, int 
     for (int u0 = wave * 64; TILE && u0 < g.nunits; u0 += 256) {
         const int u = u0 + lane;
         if (u < g.nunits) {
-            const unsigned q = (unsigned)u / UPE;
-            const unsigned pix = div32(q, g.d_cbv), cv = q - pix * CBV;
+            // bf16: unit u = (pixel, cv).  fp32: unit u = (pixel, half, cv) -- the two 16-byte halves of an 8-channel vector
+            // sit in separate planes, so that lanes with consecutive cv read consecutive 16-byte slots (32-byte vectors
+            // put every ds_read_b128 of the taps on half of the banks: PMC, two conflict cycles per busy cycle)
+            const unsigned r = div32(u, g.d_cbv), cv = u - r * CBV;
+            const unsigned pix = UPE == 2 ? r >> 1 : r, half = UPE == 2 ? r & 1u : 0u;
             const unsigned iy = div32(pix, g.d_iw), ix = pix - iy * IW;
             const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
             const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && (int)cv < ncv;
-            const int off = ((gy * a.W + gx) * a.C + (cv0 + (int)cv) * 8) * (int)sizeof(T) + (u % UPE) * 16;
+            const int off = ((gy * a.W + gx) * a.C + (cv0 + (int)cv) * 8) * (int)sizeof(T) + (int)half * 16;
             const unsigned char* src = ok ? Xn + off : Z;
             __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + u0 * 16), 16, 0, 0);
         }
@@ -128,7 +131,9 @@ FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const f
 #pragma unroll
             for (int j = 0; j < 4; ++j) { acc[o][j] = b0[j]; acc[o][4 + j] = b1[j]; }
     }
-    const V8<T>* row = tile + ((oy * S) * IW + sx * SW * S) * PP + cv;
+    // 16-byte slots: bf16 (pixel * PP + cv); fp32 ((pixel * 2 + half) * PP + cv), see dw_stage
+    constexpr int HP = sizeof(T) == 4 ? 2 : 1;
+    const unsigned char* row = reinterpret_cast<const unsigned char*>(tile) + ((((oy * S) * IW + sx * SW * S) * HP) * PP + cv) * 16;
     const float* wrow = wl + cv * 4;
 #pragma unroll 1
     for (int ky = 0; ky < K; ++ky) {
@@ -142,7 +147,14 @@ FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const f
         }
 #pragma unroll
         for (int ix = 0; ix < IWS; ++ix) {
-            const Vec8f v = load8(reinterpret_cast<const T*>(row + ix * PP));
+            Vec8f v;
+            if constexpr (HP == 2) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(row + (ix * 2) * PP * 16), v1 = *reinterpret_cast<const f32x4*>(row + (ix * 2 + 1) * PP * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v.v[j] = v0[j]; v.v[4 + j] = v1[j]; }
+            } else {
+                v = load8(reinterpret_cast<const T*>(row + ix * PP * 16));
+            }
 #pragma unroll
             for (int o = 0; o < SW; ++o) {
                 const int kx = ix - o * S;
@@ -152,7 +164,7 @@ FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const f
                 }
             }
         }
-        row += IW * PP;
+        row += IW * HP * PP * 16;
         wrow += K * 2 * CBV * 4;
     }
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
@@ -431,7 +443,8 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
             }
         }
         // 8-channel group cg of this pixel sits at (pix * PP + cg) vectors of sizeof(V8<T>) bytes
-        unsigned char* dst = smem + ((size_t)pix * g.PP + 2 * he) * sizeof(V8<T>);
+        // (fp32: (pixel * 2 + half) * PP + cg in 16-byte slots, the layout dw_item reads)
+        unsigned char* dst = smem + ((size_t)pix * g.PP * (F32 ? 2 : 1) + 2 * he) * 16;
 #pragma unroll
         for (int t = 0; t < NTE; ++t) {
             f32x16 acc;
@@ -473,8 +486,8 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { r0[i] = (!MASK || inimg) ? v.v[i] : 0.f; r1[i] = (!MASK || inimg) ? v.v[4 + i] : 0.f; }
                     if (live) {
-                        *reinterpret_cast<f32x4*>(dst + (4 * t + gg) * 32) = r0;
-                        *reinterpret_cast<f32x4*>(dst + (4 * t + gg) * 32 + 16) = r1;
+                        *reinterpret_cast<f32x4*>(dst + (4 * t + gg) * 16) = r0;
+                        *reinterpret_cast<f32x4*>(dst + (g.PP + 4 * t + gg) * 16) = r1;
                     }
                 } else {
                     u32x4 r;
