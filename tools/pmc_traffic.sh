@@ -1,5 +1,6 @@
 # usage (on the GPU box): bash tools/pmc_traffic.sh <model> <batch> [precision]
-# two separate counter passes (FETCH_SIZE, WRITE_SIZE), kernel-trace only -- then tools/hbm_traffic.py
+# two separate counter passes (FETCH_SIZE, WRITE_SIZE), kernel-trace only -- then tools/hbm_traffic.py with
+# <steps+warmup> = 14: 3 timed + 1 warm-up + the 10 pre-warm steps bench.py runs when the layer profile is off
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
