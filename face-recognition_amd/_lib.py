@@ -40,6 +40,10 @@ _SIGS = {
     "fr_plan_num_launches": (C.c_int, [C.c_void_p]),
     "fr_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fr_embed_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "fr_embed_graph_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "fr_embed_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fr_embed_graph_nodes": (C.c_int, [C.c_void_p]),
+    "fr_embed_graph_destroy": (C.c_int, [C.c_void_p]),
     "fr_align_faces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fr_embed_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                C.c_int, C.c_void_p]),

@@ -761,6 +761,68 @@ static int embed_split(const fr_plan* plan, const void* xv, bool x_u8, int batch
     return embed_impl(plan, xv, x_u8, batch, out, workspace, workspace_bytes, stream, -1, nullptr, nullptr);
 }
 
+// ---- hipGraph replay of one plan at one batch size (small batches: a forward is ~60 launches, launch-latency bound) ----
+struct fr_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int device = 0, nodes = 0;
+};
+
+extern "C" int fr_embed_graph_destroy(fr_graph* g) {
+    if (!g) return FR_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return FR_OK;
+}
+
+extern "C" int fr_embed_graph_create(const fr_plan* plan, const void* x, int x_is_u8, int batch, float* out,
+                                     void* workspace, size_t workspace_bytes, fr_graph** out_graph) {
+    if (!plan || !x || !out || !workspace || !out_graph || batch <= 0) FR_FAIL(FR_ERR_ARG, "fr_embed_graph_create: bad arguments");
+    int dev = 0;
+    FR_HIP_CHECK(hipGetDevice(&dev));
+    if (dev != plan->device) FR_FAIL(FR_ERR_ARG, "fr_embed_graph_create: the plan belongs to another device");
+    hipStream_t cs = nullptr;
+    FR_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    std::unique_ptr<fr_graph> g(new fr_graph);
+    g->device = dev;
+    // eager once: code objects loaded, hipFuncSetAttribute done, errors of the shape reported outside a capture
+    int rc = embed_impl(plan, x, x_is_u8 != 0, batch, out, workspace, workspace_bytes, cs, -1, nullptr, nullptr);
+    hipError_t he = hipStreamSynchronize(cs);
+    if (rc == FR_OK && he != hipSuccess) { fr_set_error(std::string("fr_embed_graph_create: ") + hipGetErrorString(he)); rc = FR_ERR_HIP; }
+    if (rc == FR_OK) {
+        he = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
+        if (he != hipSuccess) { fr_set_error(std::string("hipStreamBeginCapture: ") + hipGetErrorString(he)); rc = FR_ERR_HIP; }
+        else {
+            rc = embed_impl(plan, x, x_is_u8 != 0, batch, out, workspace, workspace_bytes, cs, -1, nullptr, nullptr);
+            const std::string first = rc ? g_last_error : std::string();
+            he = hipStreamEndCapture(cs, &g->graph);            // always: the stream must leave capture mode
+            if (rc) fr_set_error(first);
+            else if (he != hipSuccess || !g->graph) { fr_set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(he)); rc = FR_ERR_HIP; }
+        }
+    }
+    if (rc == FR_OK) {
+        he = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+        if (he != hipSuccess) { fr_set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(he)); rc = FR_ERR_HIP; }
+    }
+    if (rc == FR_OK) {
+        size_t n = 0;
+        if (hipGraphGetNodes(g->graph, nullptr, &n) == hipSuccess) g->nodes = (int)n;
+    }
+    (void)hipStreamDestroy(cs);
+    if (rc) { fr_embed_graph_destroy(g.release()); return rc; }
+    *out_graph = g.release();
+    return FR_OK;
+}
+
+extern "C" int fr_embed_graph_launch(fr_graph* g, void* stream) {
+    if (!g || !g->exec) FR_FAIL(FR_ERR_ARG, "fr_embed_graph_launch: no graph");
+    FR_HIP_CHECK(hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)));
+    return FR_OK;
+}
+
+extern "C" int fr_embed_graph_nodes(const fr_graph* g) { return g ? g->nodes : FR_ERR_ARG; }
+
 extern "C" int fr_embed(const fr_plan* plan, const float* x, int batch, float* out,
                         void* workspace, size_t workspace_bytes, void* stream) {
     return embed_split(plan, x, false, batch, out, workspace, workspace_bytes, stream);

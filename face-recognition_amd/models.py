@@ -44,6 +44,15 @@ def default_precision() -> str:
     return os.environ.get("FR_PRECISION", "auto")
 
 
+def graph_max_batch() -> int:
+    """Largest batch that ``model(x)`` runs as a hipGraph replay (fr_embed_graph_*).  Off by default (0): measured on
+    mobilenetv3_large, a replay takes the same GPU time as the eager launches (0.60 ms at batch 1: the 59 dependent
+    kernels, ~10 us each, set the latency, not the launches) and a third of the HOST time (0.07 vs 0.18-0.22 ms per
+    forward), so it pays only for a serving loop whose host thread is the bottleneck: ``FR_GRAPH_MAX=64``, or
+    ``model.plan(device).graph(batch)`` for explicit static buffers."""
+    return int(os.environ.get("FR_GRAPH_MAX", "0"))
+
+
 def default_fuse() -> bool:
     """Cross-layer fusion (depthwise + following 1x1 conv in one kernel, k_dw.hip:dwp_kernel) is
     bit-identical to the separate kernels and on by default; env FR_FUSE=0 turns it off.
@@ -249,6 +258,7 @@ class _Plan:
         self.handle = handle
         self.precision = precision
         self._ws: Optional[torch.Tensor] = None
+        self._graphs: Dict[Tuple[int, bool, int], "EmbedGraph"] = {}
         c, h, w = C.c_int(), C.c_int(), C.c_int()
         self.dims = []
         for i in range(self.n_layers):
@@ -257,6 +267,9 @@ class _Plan:
 
     def close(self) -> None:
         if self.handle:
+            for g in self._graphs.values():
+                g.close()
+            self._graphs = {}
             ops.drop_workspace(int(self.handle.value))
             self.lib.fr_plan_destroy(self.handle)
             self.handle = None
@@ -292,7 +305,21 @@ class _Plan:
             rows.append((self.names[i], nm.value.decode(), float(ms[i]), self.srcs[i]))
         return rows
 
+    def graph(self, batch: int, u8: bool = False) -> "EmbedGraph":
+        """The hipGraph replay of this plan at ``batch`` for the current stream (created on first use)."""
+        key = (batch, u8, torch.cuda.current_stream(self.device).cuda_stream)
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = EmbedGraph(self, batch, u8)
+        return g
+
+    def _replay(self, n: int) -> bool:
+        return 0 < n <= graph_max_batch() and not torch.cuda.is_current_stream_capturing()
+
     def run_u8(self, x: torch.Tensor) -> torch.Tensor:
+        if self._replay(x.shape[0]):
+            with torch.cuda.device(self.device):
+                return self.graph(x.shape[0], True)(x).clone()
         c, h, w = self.dims[-1]
         return torch.ops.fr_hip.embed_u8(x, int(self.handle.value), c, h, w)        # ops.py -> fr_embed_u8
 
@@ -304,6 +331,9 @@ class _Plan:
         if n == 0:
             return out if tap < 0 else (out, None)
         if tap < 0:
+            if self._replay(n):
+                with torch.cuda.device(self.device):
+                    return self.graph(n, False)(x).clone()
             c, h, w = self.dims[-1]
             return torch.ops.fr_hip.embed(x, int(self.handle.value), c, h, w)      # ops.py -> fr_embed
         ws = self.workspace(n)
@@ -313,6 +343,52 @@ class _Plan:
             _lib.check(self.lib.fr_embed_tap(self.handle, x.data_ptr(), n, out.data_ptr(), ws.data_ptr(), ws.numel(),
                                              stream, tap, tap_out.data_ptr()), "fr_embed_tap")
             return out, tap_out
+
+
+class EmbedGraph:
+    """One plan at one batch size as a hipGraph bound to static buffers (include/fr_hip.h: fr_embed_graph_*): the
+    serving-loop form of ``model(x)`` for the reference's per-image loops (inference.py:150-153, evaluate.py:517-555).
+    ``g(x)`` copies ``x`` (GPU or pinned/pageable CPU tensor of the static shape) into ``g.x``, enqueues one replay on the
+    current stream and returns ``g.out`` -- the SAME tensor every call, overwritten by the next one."""
+
+    def __init__(self, plan: "_Plan", batch: int, u8: bool = False) -> None:
+        self.plan, self.batch, self.u8 = plan, batch, u8
+        dev = plan.device
+        self.x = (torch.zeros((batch, 112, 112, 3), dtype=torch.uint8, device=dev) if u8
+                  else torch.zeros((batch, 3, 112, 112), dtype=torch.float32, device=dev))
+        d = plan.dims[-1]
+        self.out = torch.empty((batch,) + ((d[0],) if d[1:] == (1, 1) else d), dtype=torch.float32, device=dev)
+        need = C.c_size_t()
+        _lib.check(plan.lib.fr_plan_workspace_bytes(plan.handle, batch, C.byref(need)), "fr_plan_workspace_bytes")
+        self.ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        self.handle = C.c_void_p()
+        torch.cuda.current_stream(dev).synchronize()          # the buffers exist before the private capture stream touches them
+        with torch.cuda.device(dev):
+            _lib.check(plan.lib.fr_embed_graph_create(plan.handle, self.x.data_ptr(), int(u8), batch, self.out.data_ptr(),
+                                                      self.ws.data_ptr(), self.ws.numel(), C.byref(self.handle)), "fr_embed_graph_create")
+        self.nodes = int(plan.lib.fr_embed_graph_nodes(self.handle))
+
+    def launch(self) -> torch.Tensor:
+        _lib.check(self.plan.lib.fr_embed_graph_launch(self.handle, torch.cuda.current_stream(self.plan.device).cuda_stream),
+                   "fr_embed_graph_launch")
+        return self.out
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if tuple(x.shape) != tuple(self.x.shape) or x.dtype != self.x.dtype:
+            raise ValueError(f"EmbedGraph: expected {self.x.dtype} {tuple(self.x.shape)}, got {x.dtype} {tuple(x.shape)}")
+        self.x.copy_(x, non_blocking=True)
+        return self.launch()
+
+    def close(self) -> None:
+        if self.handle:
+            self.plan.lib.fr_embed_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _mobilenet_init(net: nn.Module) -> None:

@@ -125,6 +125,22 @@ int fr_embed_u8(const fr_plan* plan, const unsigned char* x_nhwc, int batch, flo
  * SURVEY.md 8(f) rank 4. */
 int fr_align_faces(const unsigned char* const* images, const int* sizes_hw, const double* inv_matrices,
                    int n, int out_size, unsigned char* out, void* stream);
+/* Replay form of fr_embed / fr_embed_u8 for small batches.  Replaces: the reference's per-image loops -- `model(tensor)` once
+ * per image at inference.py:150-153 (extract_batch_embeddings), :109-123 (extract_features) and evaluate.py:517-555 (two bs-1
+ * forwards per LFW pair) -- where a forward is ~60 launches of a few microseconds each and the GPU idles between them.
+ * fr_embed_graph_create runs the plan once eagerly on a private stream (loads the code objects, sets the kernels' LDS limits),
+ * then captures the same launch sequence into a hipGraph and instantiates it.  The graph is bound to the pointers given here:
+ * x (float32 [batch,3,h,w] NCHW, or uint8 [batch,h,w,3] when x_is_u8), out and workspace must stay allocated and at the same
+ * addresses until fr_embed_graph_destroy; the caller refills x and reads out around each launch.  The batch is never split
+ * over auxiliary streams (single-stream capture); results are bit-identical to fr_embed on the same input.
+ * fr_embed_graph_launch enqueues one replay on `stream` (asynchronous; replays of one graph must not overlap).
+ * fr_embed_graph_nodes returns the number of kernel nodes captured (diagnostics), negative on error. */
+typedef struct fr_graph fr_graph;
+int fr_embed_graph_create(const fr_plan* plan, const void* x, int x_is_u8, int batch, float* out,
+                          void* workspace, size_t workspace_bytes, fr_graph** out_graph);
+int fr_embed_graph_launch(fr_graph* graph, void* stream);
+int fr_embed_graph_nodes(const fr_graph* graph);
+int fr_embed_graph_destroy(fr_graph* graph);
 /* Same, and additionally writes the output of layer `tap_layer` as fp32 NCHW to tap_out
  * (parity tests of intermediate blocks; no reference counterpart beyond forward hooks). */
 int fr_embed_tap(const fr_plan* plan, const float* x, int batch, float* out,

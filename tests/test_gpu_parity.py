@@ -903,3 +903,36 @@ def test_packed_exchange_merge_equals_plain_merge():
     out_i = torch.empty((Q, k), dtype=torch.int64, device=DEV)
     sm._merge(recv, Q, out_s, out_i)
     assert torch.equal(out_i, i1) and torch.equal(out_s, s1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,prec", [("mobilenetv3_large", "f32"), ("mobilenetv3_small", "bf16"), ("sphere20", "bf16")])
+def test_hipgraph_replay_equals_eager(name, prec, monkeypatch):
+    """fr_embed_graph_* (include/fr_hip.h): the captured launch sequence replayed on static buffers gives the bits of
+    fr_embed, for new inputs on every replay, for the uint8 form, and through model(x) with FR_GRAPH_MAX set."""
+    import face_recognition_amd as fr
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    m = fr.get_network(name).to(dev).eval()
+    m.precision = prec
+    plan = m.plan(dev)
+    for b in (1, 5):
+        g = plan.graph(b)
+        assert g.nodes >= 20
+        for seed in (0, 1):
+            x = torch.rand((b, 3, 112, 112), generator=torch.Generator().manual_seed(seed)) * 2 - 1      # CPU tensor: H2D into the static buffer
+            want = m(x.to(dev))
+            got = g(x)
+            assert got.data_ptr() == g.out.data_ptr()
+            assert torch.equal(got, want)
+    u8 = torch.randint(0, 256, (3, 112, 112, 3), dtype=torch.uint8, device=dev)
+    assert torch.equal(plan.graph(3, u8=True)(u8), m.forward_u8(u8))
+    with pytest.raises(ValueError):
+        plan.graph(1)(torch.zeros((2, 3, 112, 112), device=dev))
+    monkeypatch.setenv("FR_GRAPH_MAX", "8")
+    x = torch.rand((4, 3, 112, 112), device=dev) * 2 - 1
+    y = m(x)
+    monkeypatch.setenv("FR_GRAPH_MAX", "0")
+    assert torch.equal(y, m(x))
+    assert (4, False, torch.cuda.current_stream(dev).cuda_stream) in plan._graphs
+    m.invalidate()                                             # destroys the graphs with the plan
