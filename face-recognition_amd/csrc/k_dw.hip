@@ -445,19 +445,25 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
         // 8-channel group cg of this pixel sits at (pix * PP + cg) vectors of sizeof(V8<T>) bytes
         // (fp32: (pixel * 2 + half) * PP + cg in 16-byte slots, the layout dw_item reads)
         unsigned char* dst = smem + ((size_t)pix * g.PP * (F32 ? 2 : 1) + 2 * he) * 16;
+        // all channel tiles' MFMAs first, then their epilogues: an epilogue right behind its own (single) MFMA waits out
+        // the MFMA's latency in s_nops, once per tile, with one wave per SIMD and block to hide it
+        f32x16 accs[NTE];
 #pragma unroll
         for (int t = 0; t < NTE; ++t) {
-            f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) accs[t][r] = 0.f;
 #pragma unroll
             for (int sk = 0; sk < KSE; ++sk) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][0], xf[sk][0], acc, 0, 0, 0);
+                accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][0], xf[sk][0], accs[t], 0, 0, 0);
                 if constexpr (F32) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][0], xf[sk][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][1], xf[sk][0], acc, 0, 0, 0);
+                    accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][0], xf[sk][1], accs[t], 0, 0, 0);
+                    accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][1], xf[sk][0], accs[t], 0, 0, 0);
                 }
             }
+        }
+#pragma unroll
+        for (int t = 0; t < NTE; ++t) {
+            const f32x16& acc = accs[t];
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg) {
                 const int c = 32 * t + 16 * he + 8 * gg;
