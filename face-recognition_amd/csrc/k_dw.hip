@@ -269,18 +269,25 @@ struct DwTileEntry { int C, Ho, k, s, TH, TW, CBV; };
 static const DwTileEntry kDwTiles[] = {
 #include "dw_tiles.inc"
 };
+static const DwTileEntry kDwTilesF32[] = {        // fp32 plans (tools/dw_probe.py <model> 512 f32)
+#include "dw_tiles_f32.inc"
+};
 
 static void dw_pick_tile(bool f32, int k, int s, DwArgs& a) {
     const int CV = a.C / 8;
     const int sw = s == 2 ? 2 : 4;
-    if (!f32 && a.Ho == a.Wo) {
-        for (const DwTileEntry& e : kDwTiles)
+    if (a.Ho == a.Wo) {
+        const DwTileEntry* tb = f32 ? kDwTilesF32 : kDwTiles;
+        const size_t ne = f32 ? sizeof(kDwTilesF32) / sizeof(DwTileEntry) : sizeof(kDwTiles) / sizeof(DwTileEntry);
+        for (size_t i = 0; i < ne; ++i) {
+            const DwTileEntry& e = tb[i];
             if (e.C == a.C && e.Ho == a.Ho && e.k == k && e.s == s && e.TW % sw == 0 && e.CBV <= CV &&
-                e.TH * (e.TW / sw) * e.CBV <= 512 && dw_lds_bytes(false, k, s, e.TH, e.TW, e.CBV) <= 60 * 1024) {
+                e.TH * (e.TW / sw) * e.CBV <= 512 && dw_lds_bytes(f32, k, s, e.TH, e.TW, e.CBV) <= 60 * 1024) {
                 a.TH = e.TH; a.TW = e.TW; a.CBV = e.CBV;
                 a.tiles_y = cdiv(a.Ho, e.TH); a.tiles_x = cdiv(a.Wo, e.TW); a.cchunks = cdiv(CV, e.CBV);
                 return;
             }
+        }
     }
     double best = 1e30;
     const int ths[] = {2, 4, 7, 8, 14, 16};

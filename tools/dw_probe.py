@@ -1,6 +1,8 @@
 """Sweep depthwise tile shapes (TH, TW, CBV) per layer shape on the GPU via the FR_DW_TILE override and
-print the best few per shape.  Output feeds the table in csrc/k_dw.hip:dw_pick_tile."""
+print the best few per shape.  Output feeds the tables in csrc/k_dw.hip:dw_pick_tile.
+Usage (GPU): python tools/dw_probe.py <model> <batch> [bf16|f32]"""
 import os, sys, itertools
+os.environ["FR_SE_FUSE"] = "0"      # no pooling partials: their buffer is sized for the default tiling when the plan is created
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import face_recognition_amd as fr
@@ -10,14 +12,16 @@ batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = fr.get_network(model_name).to(dev).eval()
-model.precision = "bf16"
+prec = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+model.precision = prec
+ES = 32 if prec == "f32" else 16
 x = (torch.rand((batch, 3, 112, 112)) * 2 - 1).to(dev)
 plan = model.plan(dev)
 g = fr.models._Graph(); model.lower(g)
 
 def lds_bytes(k, s, th, tw, cbv):
     ih, iw = (th - 1) * s + k, (tw - 1) * s + k
-    return ih * iw * cbv * 16 + k * k * cbv * 32 + cbv * 64
+    return ih * iw * cbv * ES + k * k * cbv * 32 + cbv * 64
 
 def layer_ms(reps=3):
     acc = None
@@ -43,6 +47,7 @@ for (c, ho, k, s), idx in shapes.items():
             for cbv in sorted({cv, (cv + 1) // 2, (cv + 2) // 3, (cv + 3) // 4, (cv + 4) // 5, (cv + 5) // 6, (cv + 7) // 8, 16, 12, 10, 8, 6, 5, 4, 3, 2, 1}):
                 if cbv < 1 or cbv > min(cv, 16): continue
                 if lds_bytes(k, s, th, tw, cbv) > 64 * 1024: continue
+                if th * (tw // (2 if s == 2 else 4)) * cbv > 512: continue        # work items per tile (dw_pick_tile)
                 os.environ["FR_DW_TILE"] = f"{c},{ho},{k},{s},{th},{tw},{cbv}"
                 ms = layer_ms(2)
                 res.append((sum(ms[i] for i in idx) / len(idx), th, tw, cbv, lds_bytes(k, s, th, tw, cbv)))
