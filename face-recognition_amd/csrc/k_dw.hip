@@ -276,7 +276,8 @@ static const DwTileEntry kDwTilesF32[] = {        // fp32 plans (tools/dw_probe.
 static void dw_pick_tile(bool f32, int k, int s, DwArgs& a) {
     const int CV = a.C / 8;
     const int sw = s == 2 ? 2 : 4;
-    if (a.Ho == a.Wo) {
+    static const bool use_table = !(getenv("FR_DW_TABLE") && atoi(getenv("FR_DW_TABLE")) == 0);     // 0: cost model only (tools/dw_probe.py measures against it)
+    if (a.Ho == a.Wo && use_table) {
         const DwTileEntry* tb = f32 ? kDwTilesF32 : kDwTiles;
         const size_t ne = f32 ? sizeof(kDwTilesF32) / sizeof(DwTileEntry) : sizeof(kDwTiles) / sizeof(DwTileEntry);
         for (size_t i = 0; i < ne; ++i) {

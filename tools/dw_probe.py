@@ -2,6 +2,7 @@
 print the best few per shape.  Output feeds the tables in csrc/k_dw.hip:dw_pick_tile.
 Usage (GPU): python tools/dw_probe.py <model> <batch> [bf16|f32]"""
 import os, sys, itertools
+os.environ["FR_DW_TABLE"] = "0"     # "default" below = the cost model of dw_pick_tile, which tools/make_dw_table.py compares against
 os.environ["FR_SE_FUSE"] = "0"      # no pooling partials: their buffer is sized for the default tiling when the plan is created
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
