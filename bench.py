@@ -415,6 +415,23 @@ def main():
         line["precision_modes"] = {a.precision: mine, other: theirs, "product_default": f"auto -> {model.auto_precision}",
                                    "parity": "bf16 meets cos >= 0.9999 on this config's random-init weights only; f32 (fp32 "
                                              "activations, split-bf16 operands, 3 MFMA passes) meets it on every backbone, raw and BN-calibrated"}
+    if rank == 0 and world == 1 and not a.no_modes:
+        # the reference's own mode: one image per forward (inference.py:150-153, evaluate.py:517-555), next to cpu_baseline.batch1_value
+        x1 = x[:1].contiguous()
+        b1 = {}
+        for prec in (a.precision, "f32" if a.precision == "bf16" else "bf16"):
+            for _ in range(30):
+                model(x1, precision=prec)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(300):
+                model(x1, precision=prec)
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) / 300 * 1e3
+            b1[prec] = {"ms_per_forward": round(ms, 4), "value": round(1e3 / ms, 1), "unit": "embeddings/sec"}
+        b1["note"] = "batch 1, back-to-back forwards on one stream: the latency of the ~60 dependent kernels of a forward, not throughput"
+        line["batch1"] = b1
+        model.invalidate()
     del x, xin, model
     torch.cuda.empty_cache()
 
