@@ -724,8 +724,11 @@ static const DwpTileEntry kDwpTiles[] = {
 // so the winners are small tiles; shapes not listed use the cost model
 static const DwpTileEntry kDwpTilesF32[] = {
     {16, 0, 56, 3, 2, 32, 14, 8}, {32, 0, 28, 3, 2, 64, 4, 28}, {32, 0, 112, 3, 1, 16, 16, 16}, {16, 0, 112, 3, 1, 16, 16, 28},
-    {96, 16, 56, 3, 2, 24, 2, 8}, {64, 16, 56, 3, 2, 24, 4, 8}, {72, 24, 56, 3, 1, 24, 8, 4}, {72, 16, 28, 3, 2, 24, 7, 4},
-    {88, 24, 28, 3, 1, 24, 8, 4},
+    {64, 16, 56, 3, 2, 24, 4, 8}, {72, 16, 28, 3, 2, 24, 7, 4}, {32, 0, 56, 3, 1, 32, 8, 28},
+    // one block per CU (80-150 KB), measured against the best tile under 80 KB:
+    {72, 24, 56, 3, 1, 24, 14, 8},        // mobilenetv3_large features.3: 0.437 vs 0.603 ms
+    {96, 16, 56, 3, 2, 24, 7, 8},         // mobilenetv2 features.2: 0.871 vs 1.10 ms
+    {88, 24, 28, 3, 1, 24, 4, 28},        // mobilenetv3_small features.3: 0.148 vs 0.202 ms
 };
 
 static bool dwp_pick(bool f32, int k, int s, int C, int Ho, int Wo, int cout, int cin, DwpPlan* out) {
@@ -748,7 +751,10 @@ static bool dwp_pick(bool f32, int k, int s, int C, int Ho, int Wo, int cout, in
     // row pitch of the LDS depthwise result (one bf16 plane): an odd number of 16-byte slots keeps the b128
     // fragment reads of 8 consecutive rows on distinct bank groups
     const int pitch = C * 2 + ((CV & 1) ? 32 : 16);
-    const size_t cap = f32 ? 80 * 1024 : 64 * 1024;
+    static const int cap_env = getenv("FR_DWP_CAP_KB") ? atoi(getenv("FR_DWP_CAP_KB")) : 0;            // tuning: LDS cap of the fused kernels
+    // fp32 plans may take ONE block per CU (up to 150 KB): the hi+lo planes leave so few pixels per tile at 80 KB that the expand conv
+    // is recomputed 1.9x on the halo (72 channels: 8x4 tiles); a 14x8 tile in 100 KB was 28 % faster (0.44 vs 0.60 ms per 512 images)
+    const size_t cap = cap_env > 0 ? (size_t)cap_env * 1024 : (f32 ? 150 * 1024 : 64 * 1024);
     double best = 1e30; bool found = false;
     const int ths[] = {2, 4, 7, 8, 14, 16};
     const int tws[] = {4, 8, 16, 28, 32, 56};
@@ -782,7 +788,7 @@ static bool dwp_pick(bool f32, int k, int s, int C, int Ho, int Wo, int cout, in
         if (lds > cap) continue;
         const double useful = (double)std::min(th, Ho) * std::min(tw, Wo);
         // staged input per useful output, padded MFMA rows, and a preference for >= 3 blocks per CU
-        double cost = (IH * IW) / useful + 0.5 * npx_pad / useful + (lds > 53 * 1024 ? 0.4 : lds > 40 * 1024 ? 0.2 : 0.0) + (items < 192 ? 0.5 : 0.0);
+        double cost = (IH * IW) / useful + 0.5 * npx_pad / useful + (lds > 80 * 1024 ? 1.0 : lds > 53 * 1024 ? 0.4 : lds > 40 * 1024 ? 0.2 : 0.0) + (items < 192 ? 0.5 : 0.0);
         cost *= (double)cdiv(Ho, th) * th * cdiv(Wo, tw) * tw / ((double)Ho * Wo);   // edge waste
         if (cost < best) {
             best = cost; found = true;
