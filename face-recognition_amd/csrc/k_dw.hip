@@ -738,7 +738,8 @@ static bool dwp_pick(bool f32, int k, int s, int C, int Ho, int Wo, int cout, in
     // fp32 plans without the expand conv: measured per shape on mobilenetv1 / v3 (512-image launches), the fused form wins
     // for 16..32 channels (0.146 vs 0.170 ms, 0.130 vs 0.178, 0.079 vs 0.094, 0.34 vs 0.43) and loses for 8 channels
     // (0.269 vs 0.242) and from 64 channels up (0.104 vs 0.092, 0.083 vs 0.055): the hi + lo planes leave too few pixels per tile
-    if (f32 && !cin && (C < 16 || C > 32)) return false;
+    static const int f32_cmax = getenv("FR_DWP_F32_CMAX") ? atoi(getenv("FR_DWP_F32_CMAX")) : 32;     // tuning
+    if (f32 && !cin && (C < 16 || C > f32_cmax)) return false;
     // bf16 plans, same measurement (mobilenetv1): wins for 16..64 channels (0.066 vs 0.078 ms, 0.067 vs 0.086, 0.039 vs 0.051,
     // 0.054 vs 0.057), loses for 8 (0.146 vs 0.132) and badly for 128 channels on the 14x14 maps (0.076 vs 0.039 per layer)
     if (!f32 && !cin && (C < 16 || C > 64)) return false;
