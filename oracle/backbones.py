@@ -358,3 +358,45 @@ def calibrate_bn(net: nn.Module, batches: Sequence[torch.Tensor]) -> None:
     net.eval()
     for m in bns:
         m.momentum = 0.1
+
+
+def trained_like(sd, seed: int = 2024):
+    """A deterministic, seed-regenerable "trained-like" variant of a state_dict.  Not a
+    reference function: it only produces a harder weight set than the reference's init
+    (models/sphereface.py:89-96: N(0, 0.01) bias-free convs, PReLU slopes 0.25, zero biases; mobilenet init
+    models/mobilenetv3.py:163-175) so that the precision policy is tested on weights with O(1) differences in
+    dynamic range between channels.  The SAME function is applied to the reference model's state_dict in
+    tests/golden/make_golden.py and to the product model's in the tests (their seeded state_dicts are identical,
+    tests/golden/state_sha256.json), so only the embeddings are committed.
+
+      * conv / linear weights: rescaled per layer to unit gain (std = g / sqrt(fan_in); g = 0.5 for the second conv
+        of a SphereFace residual block so that a stage of 16 blocks stays O(1..10)), then multiplied by a per-output-
+        channel log-normal factor exp(0.5 N(0,1));
+      * PReLU slopes ~ U[0.05, 0.5] per channel;
+      * conv / linear biases ~ N(0, 0.1); BatchNorm weight ~ U[0.5, 1.5], BatchNorm bias ~ N(0, 0.3)
+        (running statistics are left alone: calibrate them afterwards with ``calibrate_bn``).
+    Keys are visited in the dict's order with one generator, so the result depends only on (sd, seed)."""
+    g = torch.Generator().manual_seed(seed)
+    out = OrderedDict()
+    keys = list(sd.keys())
+    is_bn = {k.rsplit(".", 1)[0] for k in keys if k.endswith("running_mean")}
+    for k in keys:
+        v = sd[k].detach().clone()
+        mod, leaf = k.rsplit(".", 1)
+        if mod in is_bn:
+            if leaf == "weight":
+                v = torch.empty_like(v).uniform_(0.5, 1.5, generator=g)
+            elif leaf == "bias":
+                v = torch.empty_like(v).normal_(0.0, 0.3, generator=g)
+        elif leaf == "weight" and v.dim() == 1:                      # PReLU slopes (one per channel)
+            v = torch.empty_like(v).uniform_(0.05, 0.5, generator=g)
+        elif leaf == "weight" and v.dim() in (2, 4):
+            fan_in = v[0].numel()
+            gain = 0.5 if ".block.1.0" in k and k.startswith("layer") else 1.0
+            v = v / v.std().clamp_min(1e-30) * (gain / fan_in ** 0.5)
+            ch = torch.exp(0.5 * torch.randn(v.shape[0], generator=g))
+            v = v * ch.view(-1, *([1] * (v.dim() - 1)))
+        elif leaf == "bias":
+            v = torch.empty_like(v).normal_(0.0, 0.1, generator=g)
+        out[k] = v
+    return out

@@ -12,6 +12,8 @@ Outputs (all small):
   emb_<model>.npz          reference embeddings [8,512] fp32 (raw init, seed 0) + per-block taps
   bncal_<model>.npz        BN running stats after calibration + reference embeddings with them
   pairs.npz                64 embedding pairs, both similarity formulas, decisions at 0.35
+  trained_<model>.npz      reference embeddings on the "trained-like" weight set oracle.backbones.trained_like(seed 2024)
+                           (all 7 backbones; MobileNets: + the BN statistics calibrated on that weight set)
 """
 import hashlib
 import json
@@ -72,6 +74,32 @@ def tap_summary(t):
     return np.concatenate([[t.mean().item(), t.pow(2).mean().sqrt().item()], flat[idx].numpy()])
 
 
+def trained_like_goldens(x):
+    """The REFERENCE models on oracle.backbones.trained_like weights: per-channel log-normal
+    weight scales, PReLU slopes U[0.05, 0.5], non-zero biases, BatchNorm affine parameters away from (1, 0).
+    Only the embeddings (and, for the MobileNets, the BN statistics calibrated on these weights) are written;
+    the weights regenerate from the seed."""
+    for name, ctor in REF.items():
+        torch.manual_seed(0)
+        net = ctor().eval()
+        net.load_state_dict(ob.trained_like(net.state_dict(), seed=2024))
+        out = {}
+        if name.startswith("mobilenet"):
+            cal = torch.stack([osc.to_model_input(im) for im in
+                               osc.synthetic_faces(12, 4, seed=78).reshape(48, 112, 112, 3)])
+            ob.calibrate_bn(net, [cal[i:i + 16] for i in range(0, 48, 16)])
+            stats = {k: v.numpy() for k, v in net.state_dict().items()
+                     if k.endswith("running_mean") or k.endswith("running_var")}
+            out["keys"] = np.array(list(stats.keys()))
+            out.update({f"s{i}": v for i, v in enumerate(stats.values())})
+        with torch.no_grad():
+            y = net(x)
+            y64 = net.double()(x.double())
+        c = torch.nn.functional.cosine_similarity(y.double(), y64, dim=1)
+        np.savez_compressed(os.path.join(HERE, f"trained_{name}.npz"), emb=y.numpy(), emb64=y64.numpy(), **out)
+        print(name, "trained-like emb norm", y.norm(dim=1)[:2].tolist(), "fp32 vs fp64 cos", c.min().item())
+
+
 def main():
     torch.set_num_threads(8)
     u8 = golden_inputs()
@@ -109,6 +137,7 @@ def main():
                                 **{f"s{i}": v for i, v in enumerate(stats.values())})
             print(name, "bn-calibrated emb norm", yc.norm(dim=1)[:2].tolist())
     json.dump(shas, open(os.path.join(HERE, "state_sha256.json"), "w"), indent=1)
+    trained_like_goldens(x)
 
     # Pair scoring: 64 pairs of 512-d vectors; half correlated, a few straddling the threshold.
     rng = np.random.default_rng(5)

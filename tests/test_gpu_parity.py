@@ -174,6 +174,27 @@ def test_default_precision_meets_the_bar_on_every_backbone(name, calibrated, gol
     assert m.plan(DEV).precision == ("bf16" if name.startswith("sphere") else "f32")
 
 
+@pytest.mark.parametrize("name", ob.MODEL_NAMES)
+def test_default_precision_meets_the_bar_on_trained_like_weights(name, golden_dir, golden_x):
+    """The default precision on the "trained-like" weight set (oracle.backbones.trained_like, seed 2024: per-channel
+    log-normal weight scales, PReLU slopes U[0.05, 0.5], non-zero biases, BatchNorm affine away from (1, 0) and
+    statistics calibrated on THOSE weights) against the REFERENCE's embeddings on the same state_dict
+    (tests/golden/trained_<name>.npz).  This is the SphereFace case the raw init cannot give: residual branches as
+    large as the trunk, O(1) differences in dynamic range between channels.  Also checked with the common component
+    of the 8 embeddings removed (their mean), which is what separates two faces."""
+    from test_oracle_golden import trained_like_state
+    sd, want = trained_like_state(name, golden_dir)
+    m = product(name, sd)
+    with torch.no_grad():
+        y = m(golden_x.to(DEV)).cpu().numpy()
+    c = cos_rows(y, want)
+    mu = want.astype(np.float64).mean(0)
+    cc = cos_rows(y - mu, want - mu)
+    assert c.min() >= COS_BAR, (m.plan(DEV).precision, c)
+    assert cc.min() >= 0.999, (m.plan(DEV).precision, cc)
+    assert np.abs(np.linalg.norm(y, axis=1) / np.linalg.norm(want, axis=1) - 1).max() < 1e-2
+
+
 # measured on MI355X (tools/precision_probe.py): min cosine of the single-pass bf16 mode over the 8 golden inputs
 _BF16_MEASURED = {("mobilenetv1", False): 0.99986, ("mobilenetv2", False): 0.99990, ("mobilenetv3_small", False): 0.99995,
                   ("mobilenetv3_large", False): 0.99995, ("mobilenetv1", True): 0.9961, ("mobilenetv2", True): 0.9973,

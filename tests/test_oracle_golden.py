@@ -50,6 +50,30 @@ def test_oracle_bn_calibrated_embeddings(name, golden_dir, golden_x):
     assert np.allclose(y, ref, rtol=1e-4, atol=1e-4)
 
 
+def trained_like_state(name, golden_dir):
+    """The seeded state_dict under oracle.backbones.trained_like(seed 2024) (+ the committed BN statistics calibrated
+    on those weights, MobileNets) and the REFERENCE's embeddings on it (tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(golden_dir, f"trained_{name}.npz"))
+    sd = ob.trained_like(ob.seeded(name, 0).state_dict(), seed=2024)
+    if "keys" in g:
+        for i, k in enumerate(g["keys"]):
+            sd[str(k)] = torch.from_numpy(g[f"s{i}"])
+    return sd, g["emb"]
+
+
+@pytest.mark.parametrize("name", ["mobilenetv1", "mobilenetv3_small", "mobilenetv3_large", "sphere20", "sphere36"])
+def test_oracle_trained_like_embeddings(name, golden_dir, golden_x):
+    """The oracle on the trained-like weight set equals the reference on the same weights (fixture written by the
+    reference itself)."""
+    sd, ref = trained_like_state(name, golden_dir)
+    net = ob.seeded(name, 0)
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        y = net(golden_x).numpy()
+    assert np.allclose(y, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    assert cos_rows(y, ref).min() > 0.9999999
+
+
 def test_top_block_taps(golden_dir, golden_x):
     g = np.load(os.path.join(golden_dir, "emb_mobilenetv3_small.npz"))
     net = ob.seeded("mobilenetv3_small", 0)

@@ -27,8 +27,8 @@ def main():
     noise = np.random.default_rng(99).integers(0, 256, size=(4, 112, 112, 3), dtype=np.uint8)
     x = torch.stack([osc.to_model_input(im) for im in np.concatenate([faces, noise], 0)]).to(DEV)
     for name in ("mobilenetv1", "mobilenetv2", "mobilenetv3_small", "mobilenetv3_large", "sphere20", "sphere36", "sphere64"):
-        for cal in (False, True):
-            f = os.path.join(GOLD, ("bncal_" if cal else "emb_") + name + ".npz")
+        for cal in (False, True, "trained"):
+            f = os.path.join(GOLD, {False: "emb_", True: "bncal_", "trained": "trained_"}[cal] + name + ".npz")
             if not os.path.exists(f):
                 continue
             g = np.load(f)
@@ -36,7 +36,9 @@ def main():
             m = fr.get_network(name)
             if cal:
                 sd = ob.seeded(name, 0).state_dict()
-                for i, k in enumerate(g["keys"]):
+                if cal == "trained":
+                    sd = ob.trained_like(sd, seed=2024)
+                for i, k in enumerate(g["keys"] if "keys" in g else []):
                     sd[str(k)] = torch.from_numpy(g[f"s{i}"])
                 m.load_state_dict(sd)
             m = m.to(DEV).eval()
@@ -45,8 +47,10 @@ def main():
                 with torch.no_grad():
                     y = m(x, precision=p).cpu().numpy()
                 c = cos_rows(y, g["emb"])
-                row.append(f"{p}: min {c.min():.7f} mean {c.mean():.7f}")
-            print(f"{name:20s} {'bncal' if cal else 'raw  '}  " + "   ".join(row), flush=True)
+                mu = g["emb"].astype(np.float64).mean(0)
+                cc = cos_rows(y - mu, g["emb"] - mu)
+                row.append(f"{p}: min {c.min():.7f} mean {c.mean():.7f} centred min {cc.min():.6f}")
+            print(f"{name:20s} {({False: 'raw    ', True: 'bncal  ', 'trained': 'trained'})[cal]}  " + "   ".join(row), flush=True)
 
 
 if __name__ == "__main__":
