@@ -13,6 +13,7 @@ ranks with one packed RCCL all-gather per 32768-query chunk (configs[4]).  The J
   precision_modes                 the same config in every precision mode, "f32" being what "auto" (the product
                                   default) resolves to for the MobileNets -- each with its own roofline
   sphere64                        configs[2]: sphere64 batch 512 (MFMA roofline)
+  pairs                           configs[0] at its size: 6000 LFW-style pairs through evaluate.eval, + the CPU pair loop
   search                          configs[3] (10 M x 65536, one GPU) or configs[4] (100 M, sharded), + its CPU baseline
   cpu_baseline                    the CPU oracle (PyTorch fp32 restatement of the reference) on this box's host cores
 """
@@ -36,11 +37,6 @@ ALG_MB_PER_IMG = {"mobilenetv3_large": 17.70, "mobilenetv3_small": 5.74, "mobile
 ALG_GFLOP_PER_IMG = {"mobilenetv3_large": 0.4292, "mobilenetv3_small": 0.1104, "mobilenetv2": 0.5754, "mobilenetv1": 0.0818,
                      "sphere20": 4.0828, "sphere36": 7.782, "sphere64": 14.256}
 BASELINE_CONFIGS = {("mobilenetv3_large", 1024): "BASELINE.json configs[1]", ("sphere64", 512): "BASELINE.json configs[2]"}
-# When two kernel families are within 5 % of the largest time per step, the one earlier in this list is reported as
-# the dominant kernel, so that the choice does not flip on a 0.001 ms difference between runs.  Unfused kernels come
-# first: their algorithmic bytes are the bytes they really move.
-DOMINANT_PREFERENCE = ["pw_stream_kernel", "pw_gemm_kernel", "conv_halo16_kernel", "conv_halo_kernel", "dw_kernel", "pw_proj_kernel",
-                       "conv_glds_kernel", "dwp_kernel", "stem_kernel"]
 
 
 def synthetic_batch(batch, device, seed=0):
@@ -135,10 +131,7 @@ def roofline_records(model_name, batch, ms, plan, rows, ms_layer, pb, parts, lay
         f = fam.setdefault(kern, [0.0, 0.0, 0, 0.0])
         f[0] += t; f[1] += b + carry_b; f[2] += 1; f[3] += fl + carry_f
         carry_b = carry_f = 0.0
-    t_max = max(v[0] for v in fam.values())
-    near = [k for k, v in fam.items() if v[0] >= 0.95 * t_max]
-    near.sort(key=lambda k: (DOMINANT_PREFERENCE.index(k) if k in DOMINANT_PREFERENCE else len(DOMINANT_PREFERENCE), k))
-    dom = near[0]
+    dom = max(fam, key=lambda k: (fam[k][0], k))     # the family with the most time per step, no preference list
     t_dom, b_dom, n_dom, f_dom = fam[dom]
     out = {}
     # arithmetic intensity of the dominant family against the machine balance decides the bound
@@ -290,6 +283,92 @@ def bench_search(dev, rank, world, steps, warmup, n_gallery, n_queries):
                          "alg_flops_per_query": 2.0 * n_gallery * 512}}
 
 
+def lfw_layout_faces(n_pairs=6000, seed=1234):
+    """BASELINE.json configs[0] at its size: 12 000 synthetic 112x112 faces = 2 x 6000 pairs in LFW layout (SURVEY.md
+    8(d) config 1: 3000 "same" pairs in the 3-token form, 3000 "different" pairs in the 4-token form, header line
+    first).  A face = a low-frequency field per identity + per-image noise (vectorised form of the generator the parity
+    tests use).  Returns ({path: uint8 [112,112,3]}, annotation lines)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    n_same = n_pairs // 2
+    n_ids = n_same + (n_pairs - n_same)             # `same` ids use images 1,2; the others pair up across ids
+    t = np.linspace(0, 1, 112)
+    basis = np.stack([np.outer(np.cos(np.pi * a * t), np.cos(np.pi * b * t)).ravel() for a in range(4) for b in range(4)])
+    faces, lines = {}, [f"{n_pairs}\n"]
+    for lo in range(0, n_ids, 500):
+        ids = range(lo, min(n_ids, lo + 500))
+        co = rng.normal(size=(len(ids), 3, 16))
+        base = (co @ basis).reshape(len(ids), 3, 112, 112)
+        base /= np.abs(base).reshape(len(ids), -1).max(1)[:, None, None, None] + 1e-9
+        for j in (1, 2):
+            noise = rng.integers(-20, 21, size=base.shape, dtype=np.int16)
+            img = np.clip(127.5 + 90.0 * base + noise, 0, 255).astype(np.uint8).transpose(0, 2, 3, 1)
+            for r, i in enumerate(ids):
+                faces[os.path.join(f"id{i:05d}", f"id{i:05d}_{j:04d}.jpg")] = np.ascontiguousarray(img[r])
+    for i in range(n_same):
+        lines.append(f"id{i:05d} 1 2\n")
+    rest = list(range(n_same, n_ids))
+    for a, b in zip(rest[0::2], rest[1::2]):
+        lines.append(f"id{a:05d} 1 id{b:05d} 1\n")
+        lines.append(f"id{a:05d} 2 id{b:05d} 2\n")
+    return faces, lines[:n_pairs + 1]
+
+
+def bench_pairs(fr, dev, n_pairs=6000, cpu_seconds=10.0, cpu=True):
+    """configs[0] measured: evaluate.eval (LFW branch; evaluate.py:359-399, :512-589) over 6000 pairs of in-memory
+    faces on mobilenetv3_small in the product's default precision -- the whole call: pair parsing, dedupe, uint8 H2D,
+    fr_embed_u8, fr_cosine_pairs, the predictions array -- beside the CPU oracle's batch-1 pair loop (the
+    reference's own mode: two forwards per pair, no caching) timed on a sample."""
+    import tempfile
+    import numpy as np
+    faces, lines = lfw_layout_faces(n_pairs)
+    torch.manual_seed(0)
+    model = fr.get_network("mobilenetv3_small").to(dev).eval()
+    with tempfile.TemporaryDirectory() as root:
+        open(os.path.join(root, "lfw_ann.txt"), "w").write("".join(lines))
+        keyed = {os.path.join(root, k): v for k, v in faces.items()}
+        load = keyed.__getitem__
+        fr.evaluate.eval(model, device=dev, val_root=root, image_loader=load)           # warm-up (plan, clocks)
+        torch.cuda.synchronize(dev)
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            mean, preds, metrics = fr.evaluate.eval(model, device=dev, val_root=root, image_loader=load, compute_full_metrics=True)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / reps
+        # device part alone: the 12 000 faces resident as uint8, embed + pair cosine
+        u8 = torch.from_numpy(np.stack(list(keyed.values()))).to(dev)
+        ia = torch.arange(0, len(u8), 2, device=dev); ib = ia + 1
+        for _ in range(2):
+            e = model.forward_u8(u8); fr.cosine_pairs(e[ia], e[ib], eps=1e-5)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            e = model.forward_u8(u8); sim, _ = fr.cosine_pairs(e[ia], e[ib], eps=1e-5)
+        torch.cuda.synchronize(dev)
+        dt_dev = (time.perf_counter() - t1) / 5
+        rec = {"metric": "LFW-style pairs/sec through evaluate.eval", "value": round(len(preds) / dt, 1), "unit": "pairs/sec",
+               "pairs": int(len(preds)), "faces": len(keyed), "ms_per_eval": round(dt * 1e3, 2), "model": "mobilenetv3_small",
+               "dtype": model.plan(dev).precision, "workload": "BASELINE.json configs[0] at its size (12 000 synthetic faces, 6000 pairs, "
+               "random-init weights); the reference runs it on the CPU, here the same call runs on the GPU",
+               "device_only": {"value": round(len(ia) / dt_dev, 1), "unit": "pairs/sec", "ms": round(dt_dev * 1e3, 3),
+                               "what": "faces resident in HBM as uint8: fr_embed_u8 (12 000 images) + fr_cosine_pairs"},
+               "mean_similarity": float(mean), "decisions_same": int(metrics["true_positives"] + metrics["false_positives"])}
+        if cpu:
+            from oracle import backbones as ob, scoring as osc            # CPU baseline only
+            net = ob.seeded("mobilenetv3_small", 0)
+            n = 0
+            t2 = time.perf_counter()
+            while time.perf_counter() - t2 < cpu_seconds:
+                osc.eval_pairs(net, keyed, lines[1 + n:1 + n + 20], root); n += 20
+            dtc = time.perf_counter() - t2
+            rec["cpu_baseline"] = {"value": round(n / dtc, 2), "unit": "pairs/sec", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"{n} of the {n_pairs} pairs, batch-1 pair loop of the CPU oracle (two forwards per pair, "
+                                             f"no caching, evaluate.py:517-555), {dtc:.1f} s; whole job = {n_pairs} / value seconds (extrapolation)"}
+    model.invalidate()
+    return rec
+
+
 def launch_ranks(n):
     """--gpus N without a rank environment: start N ranks as a fresh child process group.  This process has made
     no GPU call (importing torch does not initialise HIP), and it does not exec: it waits and forwards the code."""
@@ -339,6 +418,7 @@ def main():
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the other precision mode of the headline config")
     ap.add_argument("--no-sphere64", action="store_true", help="skip the sphere64 batch-512 sub-record (configs[2])")
+    ap.add_argument("--no-pairs", action="store_true", help="skip the LFW-style pair-verification sub-record (configs[0])")
     ap.add_argument("--gallery", type=int, default=0,
                     help="1:N gallery rows in total (default: 10M on one GPU = BASELINE.json configs[3]; 100M sharded over the ranks = configs[4])")
     ap.add_argument("--queries", type=int, default=65536)
@@ -445,6 +525,10 @@ def main():
         line["sphere64"] = rec
         s64.invalidate()
         del s64, xs
+        torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not a.no_pairs:
+        line["pairs"] = bench_pairs(fr, dev, cpu=not a.no_cpu_baseline)
         torch.cuda.empty_cache()
 
     if not a.no_search:

@@ -44,6 +44,7 @@ _SIGS = {
     "fr_embed_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fr_embed_graph_nodes": (C.c_int, [C.c_void_p]),
     "fr_embed_graph_destroy": (C.c_int, [C.c_void_p]),
+    "fr_debug_fail_after": (C.c_int, [C.c_int]),
     "fr_align_faces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fr_embed_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                C.c_int, C.c_void_p]),

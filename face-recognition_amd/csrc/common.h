@@ -23,6 +23,13 @@ void fr_set_error(const std::string& msg);
 #define FR_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
     fr_set_error(std::string("launch ") + name + ": " + hipGetErrorString(e_)); return FR_ERR_HIP; } } while (0)
 
+// Kernels that may take more than the default 64 KB of dynamic LDS: raise the kernel's limit ONCE per (kernel
+// instantiation, device) to the hardware maximum (160 KB), under a mutex -- never per launch and never to the launch's own
+// size (one instantiation serves layers with different sizes: a second host thread could lower it between another
+// thread's set and launch).  The limit does not affect occupancy, the launch's actual size does.
+int fr_big_lds_once(const void* kernel);
+#define FR_BIG_LDS_ONCE(kernel, bytes) do { if ((size_t)(bytes) > 65536) { int rc_ = fr_big_lds_once((const void*)(kernel)); if (rc_) return rc_; } } while (0)
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

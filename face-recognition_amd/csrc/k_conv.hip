@@ -703,13 +703,13 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
 #define FR_CONV_HALO_LAUNCH(TI_, TJ_, WM_, WN_)                                                                         \
     do {                                                                                                                \
         auto k = conv_halo_kernel<TOut, TI_, TJ_, WM_, WN_>;                                                            \
-        if (lds > 65536) FR_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        FR_BIG_LDS_ONCE(k, lds);                                                                                        \
         hipLaunchKernelGGL(k, g, dim3(64 * WM_ * WN_), lds, st, a, rbm);                                                \
     } while (0)
 #define FR_CONV_HALO16_LAUNCH(TI_, TJ_, WM_, WN_)                                                                       \
     do {                                                                                                                \
         auto k = conv_halo16_kernel<bf16, TI_, TJ_, WM_, WN_>;                                                          \
-        if (lds > 65536) FR_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        FR_BIG_LDS_ONCE(k, lds);                                                                                        \
         hipLaunchKernelGGL(k, g, dim3(64 * WM_ * WN_), lds, st, a, rbm);                                                \
     } while (0)
                 if (a.halo == 2) {                      // weights packed in the 16x16x32 row order (bf16 output only)
@@ -745,7 +745,7 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     const size_t lds = 2 * (size_t)NS * (bn + 128) * CV_ROW;
     if (bn == 128) {
         auto k = conv_gemm_kernel<TIn, TOut, 2, 2, 2, 2>;
-        if (lds > 65536) FR_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FR_BIG_LDS_ONCE(k, lds);
         hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
     } else {
         auto k = conv_gemm_kernel<TIn, TOut, 2, 1, 1, 4>;

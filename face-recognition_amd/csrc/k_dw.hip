@@ -807,7 +807,7 @@ bool dwp_supported(bool f32, int k, int stride, int C, int Ho, int Wo, int cout,
 template <typename T>
 static int launch_dwp_t(int k, int stride, const DwpArgs& x, const DwGeom& g, const DwpPlan& pl, bool ex, dim3 grid, hipStream_t st) {
 #define FR_DWP_GO(KK, SS, KE, NE) do { auto kern = dwp_kernel<T, KK, SS, KE, NE>; \
-        if (pl.lds > 65536) FR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds)); \
+        FR_BIG_LDS_ONCE(kern, pl.lds); \
         hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, st, x, g); } while (0)
 #define FR_DWP_CASE(KK, SS) if (!ex && k == KK && stride == SS) FR_DWP_GO(KK, SS, 0, 0);
 #define FR_DWX_CASE(SS, KE, NE) if (ex && k == 3 && stride == SS && x.KSe == KE && x.NTe == NE) FR_DWP_GO(3, SS, KE, NE);

@@ -16,8 +16,7 @@
 #include "kernels.h"
 
 // Kernels that may need more than the default 64 KB of dynamic LDS raise their limit first.
-#define FR_BIG_LDS(kernel, bytes) \
-    do { if ((bytes) > 65536) FR_HIP_CHECK(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); } while (0)
+#define FR_BIG_LDS(kernel, bytes) FR_BIG_LDS_ONCE(kernel, bytes)
 
 typedef __attribute__((address_space(3))) void* pw_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* pw_glb_ptr_t;

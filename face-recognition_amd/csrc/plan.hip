@@ -3,6 +3,9 @@
 // HIP kernels.  Replaces nn.Module construction / load_state_dict / forward (inference.py:55-96,
 // :121-122; evaluate.py:179-194).
 #include <math.h>
+#include <atomic>
+#include <mutex>
+#include <set>
 #include <memory>
 #include <vector>
 
@@ -12,6 +15,18 @@
 static thread_local std::string g_last_error;
 void fr_set_error(const std::string& msg) { g_last_error = msg; }
 extern "C" const char* fr_last_error(void) { return g_last_error.c_str(); }
+
+int fr_big_lds_once(const void* kernel) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    FR_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return FR_OK;
+    FR_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.insert({kernel, dev});
+    return FR_OK;
+}
 
 namespace {
 
@@ -516,7 +531,7 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
     for (int i = 0; i < nl; ++i) {
         const Layer& L = plan->layers[i];
         const bool last = (i == nl - 1);
-        if (i == inject_fail_layer) FR_FAIL(FR_ERR_HIP, "fr_embed: injected failure (FR_FAULT_INJECT_LAYER)");
+        if (i == inject_fail_layer) FR_FAIL(FR_ERR_HIP, "fr_embed: injected failure (fr_debug_fail_after)");
         if (L.fused_next) {
             if (i == tap_layer) FR_FAIL(FR_ERR_ARG, "fr_embed_tap: this layer is fused into the next one (create the plan with FR_PLAN_NO_FUSE)");
             if (events) FR_HIP_CHECK(hipEventRecord(events[i + 1], st));
@@ -663,16 +678,22 @@ extern "C" int fr_embed_profile(const fr_plan* plan, const float* x, int batch, 
                                 void* workspace, size_t workspace_bytes, void* stream, float* layer_ms) {
     if (!plan || !layer_ms) FR_FAIL(FR_ERR_ARG, "fr_embed_profile: bad arguments");
     const int nl = (int)plan->layers.size();
-    std::vector<hipEvent_t> ev(nl + 1);
-    for (auto& e : ev) FR_HIP_CHECK(hipEventCreate(&e));
-    int rc = embed_impl(plan, x, false, batch, out, workspace, workspace_bytes, stream, -1, nullptr, ev.data());
+    std::vector<hipEvent_t> ev(nl + 1, nullptr);
+    int rc = FR_OK;
+    for (auto& e : ev) {                                  // a failed create must not leak the events made before it
+        hipError_t he = hipEventCreate(&e);
+        if (he != hipSuccess) { e = nullptr; fr_set_error(std::string("hipEventCreate: ") + hipGetErrorString(he)); rc = FR_ERR_HIP; break; }
+    }
+    if (rc == FR_OK) rc = embed_impl(plan, x, false, batch, out, workspace, workspace_bytes, stream, -1, nullptr, ev.data());
     if (rc == FR_OK) {
         hipError_t he = hipEventSynchronize(ev[nl]);
         if (he != hipSuccess) { fr_set_error(std::string("hipEventSynchronize: ") + hipGetErrorString(he)); rc = FR_ERR_HIP; }
         for (int i = 0; i < nl && rc == FR_OK; ++i)
             if (hipEventElapsedTime(&layer_ms[i], ev[i], ev[i + 1]) != hipSuccess) { fr_set_error("hipEventElapsedTime failed"); rc = FR_ERR_HIP; }
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
+    const std::string kept = rc ? g_last_error : std::string();
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (rc) fr_set_error(kept);
     return rc;
 }
 
@@ -700,6 +721,9 @@ extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char**
     }
     return FR_OK;
 }
+
+static std::atomic<int> g_fail_after{-1};
+extern "C" int fr_debug_fail_after(int layer) { g_fail_after.store(layer < 0 ? -1 : layer); return FR_OK; }
 
 static int embed_split(const fr_plan* plan, const void* xv, bool x_u8, int batch, float* out,
                        void* workspace, size_t workspace_bytes, void* stream) {
@@ -737,7 +761,9 @@ static int embed_split(const fr_plan* plan, const void* xv, bool x_u8, int batch
             };
             // test hook (tests/test_gpu_parity.py::test_split_failure_joins_auxiliary_streams): part 1 stops with an
             // error after this many layers have been enqueued on its auxiliary stream
-            const char* inj = getenv("FR_FAULT_INJECT_LAYER");
+            // (set through fr_debug_fail_after, not the environment: no getenv on the hot path, and nothing a stray
+            // environment variable of a production server can switch on)
+            const int inj = g_fail_after.load(std::memory_order_relaxed);
             for (int i = 0; i < parts && !rc; ++i) {
                 hipStream_t si = i == 0 ? st : plan->aux[i - 1];
                 if (i > 0) {
@@ -746,7 +772,7 @@ static int embed_split(const fr_plan* plan, const void* xv, bool x_u8, int batch
                 }
                 note(embed_impl(plan, x + (size_t)n0[i] * in_el, x_u8, n0[i + 1] - n0[i], out + (size_t)n0[i] * out_el,
                                 reinterpret_cast<unsigned char*>(workspace) + off[i], off[i + 1] - off[i], si, -1, nullptr, nullptr,
-                                (inj && i == 1) ? atoi(inj) : -1));
+                                (inj >= 0 && i == 1) ? inj : -1));
                 if (i > 0) {
                     const int j = hip_rc(hipEventRecord(plan->ev_join[i - 1], si), "hipEventRecord(join)");
                     note(j);
@@ -806,8 +832,15 @@ extern "C" int fr_embed_graph_create(const fr_plan* plan, const void* x, int x_i
         if (he != hipSuccess) { fr_set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(he)); rc = FR_ERR_HIP; }
     }
     if (rc == FR_OK) {
-        size_t n = 0;
-        if (hipGraphGetNodes(g->graph, nullptr, &n) == hipSuccess) g->nodes = (int)n;
+        size_t n = 0;                                       // kernel nodes only (memcpy / memset nodes of taps are not launches)
+        if (hipGraphGetNodes(g->graph, nullptr, &n) == hipSuccess && n) {
+            std::vector<hipGraphNode_t> nodes(n);
+            if (hipGraphGetNodes(g->graph, nodes.data(), &n) == hipSuccess)
+                for (size_t i = 0; i < n; ++i) {
+                    hipGraphNodeType t;
+                    if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel) ++g->nodes;
+                }
+        }
     }
     (void)hipStreamDestroy(cs);
     if (rc) { fr_embed_graph_destroy(g.release()); return rc; }
@@ -817,6 +850,9 @@ extern "C" int fr_embed_graph_create(const fr_plan* plan, const void* x, int x_i
 
 extern "C" int fr_embed_graph_launch(fr_graph* g, void* stream) {
     if (!g || !g->exec) FR_FAIL(FR_ERR_ARG, "fr_embed_graph_launch: no graph");
+    int dev = -1;
+    FR_HIP_CHECK(hipGetDevice(&dev));
+    if (dev != g->device) FR_FAIL(FR_ERR_ARG, "fr_embed_graph_launch: the graph belongs to another device than the current one");
     FR_HIP_CHECK(hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)));
     return FR_OK;
 }

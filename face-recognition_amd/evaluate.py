@@ -140,4 +140,11 @@ def eval(model, model_path=None, device=None, val_dataset="lfw", val_root="data/
     metrics = {"mean_similarity": mean_similarity, "std_similarity": np.std(similarities)}
     if compute_full_metrics:
         metrics.update(compute_metrics_from_predictions(predicts, threshold))
+    if save_metrics_path is not None:
+        # evaluate.py:578-586 writes ROC / confusion-matrix plots there (sklearn + matplotlib reporting, SURVEY.md 2
+        # #7: out of scope of the hot path) -- say so instead of silently ignoring the argument.
+        import warnings
+        warnings.warn(f"save_metrics_path={save_metrics_path!r}: metric plots are not written by this implementation "
+                      "(out of scope of the embed-and-match path); the returned metrics dict is complete", RuntimeWarning,
+                      stacklevel=2)
     return mean_similarity, predicts, metrics

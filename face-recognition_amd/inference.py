@@ -124,19 +124,20 @@ def extract_batch_embeddings(model, device, image_folder: str, output_file: str 
     embeddings_dict = {}
     print(f"Extracting embeddings from {len(image_files)} images...")
     for lo in range(0, len(image_files), batch_size):
-        names, faces = [], []
+        faces, report = [], []                     # report: (file name, row in `faces` | None, error) in FILE order
         for img_path in image_files[lo:lo + batch_size]:
             try:
                 faces.append(_load_face_u8(str(img_path)))
-                names.append(img_path.name)
+                report.append((img_path.name, len(faces) - 1, None))
             except Exception as e:
-                print(f"✗ Error processing {img_path.name}: {e}")
-        if not faces:
-            continue
-        emb = embed_images(model, device, faces, batch_size).cpu().numpy()
-        for name, e in zip(names, emb):
-            embeddings_dict[name] = e.tolist()
-            print(f"✓ Processed: {name}")
+                report.append((img_path.name, None, e))
+        emb = embed_images(model, device, faces, batch_size).cpu().numpy() if faces else None
+        for name, row, err in report:              # messages interleave in file order, as inference.py:150-156
+            if err is not None:
+                print(f"✗ Error processing {name}: {err}")
+            else:
+                embeddings_dict[name] = emb[row].tolist()
+                print(f"✓ Processed: {name}")
     os.makedirs(os.path.dirname(output_file), exist_ok=True)
     with open(output_file, "w") as f:
         json.dump(embeddings_dict, f, indent=2)

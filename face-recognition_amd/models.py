@@ -369,8 +369,9 @@ class EmbedGraph:
         self.nodes = int(plan.lib.fr_embed_graph_nodes(self.handle))
 
     def launch(self) -> torch.Tensor:
-        _lib.check(self.plan.lib.fr_embed_graph_launch(self.handle, torch.cuda.current_stream(self.plan.device).cuda_stream),
-                   "fr_embed_graph_launch")
+        with torch.cuda.device(self.plan.device):
+            _lib.check(self.plan.lib.fr_embed_graph_launch(self.handle, torch.cuda.current_stream(self.plan.device).cuda_stream),
+                       "fr_embed_graph_launch")
         return self.out
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:

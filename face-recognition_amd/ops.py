@@ -38,7 +38,12 @@ _meta = torch.library.Library(_NS, "IMPL", "Meta")
 # (plan handle | 0 for search, device index, stream handle) -> scratch.  Keyed by STREAM as well: two calls enqueued
 # on different streams can overlap on the GPU, and a workspace shared between them (the same model on two streams,
 # two Matchers) would be written by both at once.  Calls on one stream are ordered, so they share.
+# Growth is bounded: at most MAX_STREAM_WORKSPACES streams per (plan, device) keep a workspace; a server that makes streams
+# per request evicts the least recently used one (its memory goes back to torch's caching allocator, which hands a block
+# only to later allocations of the stream it was allocated on, so kernels still queued on that stream are safe).
+# ``drop_stream_workspaces()`` releases them all, or those of one stream.
 _workspaces: Dict[Tuple[int, int, int], torch.Tensor] = {}
+MAX_STREAM_WORKSPACES = 8
 
 
 def _stream(dev) -> int:
@@ -47,12 +52,24 @@ def _stream(dev) -> int:
 
 def _workspace(key: int, dev: torch.device, nbytes: int) -> torch.Tensor:
     k = (key, dev.index, _stream(dev))
-    ws = _workspaces.get(k)
+    ws = _workspaces.pop(k, None)
     if ws is None or ws.numel() < nbytes:
-        _workspaces.pop(k, None)
+        ws = None
+        peers = [p for p in _workspaces if p[0] == key and p[1] == dev.index]
+        for p in peers[:max(0, len(peers) - (MAX_STREAM_WORKSPACES - 1))]:      # dict order = least recently used first
+            del _workspaces[p]
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _workspaces[k] = ws
+    _workspaces[k] = ws                                                           # (re-)inserted last = most recently used
     return ws
+
+
+def drop_stream_workspaces(stream: int = -1) -> int:
+    """Release the cached workspaces of one stream handle (``torch.cuda.Stream.cuda_stream``), or of every stream
+    (-1).  For servers that retire streams; returns the number released."""
+    ks = [k for k in _workspaces if stream == -1 or k[2] == stream]
+    for k in ks:
+        del _workspaces[k]
+    return len(ks)
 
 
 def drop_workspace(plan: int) -> None:

@@ -133,14 +133,20 @@ int fr_align_faces(const unsigned char* const* images, const int* sizes_hw, cons
  * x (float32 [batch,3,h,w] NCHW, or uint8 [batch,h,w,3] when x_is_u8), out and workspace must stay allocated and at the same
  * addresses until fr_embed_graph_destroy; the caller refills x and reads out around each launch.  The batch is never split
  * over auxiliary streams (single-stream capture); results are bit-identical to fr_embed on the same input.
- * fr_embed_graph_launch enqueues one replay on `stream` (asynchronous; replays of one graph must not overlap).
- * fr_embed_graph_nodes returns the number of kernel nodes captured (diagnostics), negative on error. */
+ * The graph holds the PLAN's weight pointers: the plan must outlive the graph (destroy the graph first).
+ * fr_embed_graph_launch enqueues one replay on `stream` (asynchronous; replays of one graph must not overlap); the graph's
+ * device must be the current device (FR_ERR_ARG otherwise).
+ * fr_embed_graph_nodes returns the number of KERNEL nodes captured (diagnostics), negative on error. */
 typedef struct fr_graph fr_graph;
 int fr_embed_graph_create(const fr_plan* plan, const void* x, int x_is_u8, int batch, float* out,
                           void* workspace, size_t workspace_bytes, fr_graph** out_graph);
 int fr_embed_graph_launch(fr_graph* graph, void* stream);
 int fr_embed_graph_nodes(const fr_graph* graph);
 int fr_embed_graph_destroy(fr_graph* graph);
+/* Test hook (no reference counterpart): after fr_debug_fail_after(L), L >= 0, the SECOND sub-batch of every split fr_embed /
+ * fr_embed_u8 call (batch >= 128) stops with FR_ERR_HIP once L layers have been enqueued on its auxiliary stream, so that the
+ * join-on-error path can be tested; fr_debug_fail_after(-1) switches it off (the initial state).  Process-wide. */
+int fr_debug_fail_after(int layer);
 /* Same, and additionally writes the output of layer `tap_layer` as fp32 NCHW to tap_out
  * (parity tests of intermediate blocks; no reference counterpart beyond forward hooks). */
 int fr_embed_tap(const fr_plan* plan, const float* x, int batch, float* out,

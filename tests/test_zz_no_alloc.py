@@ -80,3 +80,31 @@ def test_noalloc_search_makes_no_allocation_and_rejects_oversize(monkeypatch):
     monkeypatch.delenv("FR_SEARCH_QCHUNK")
     assert lib.fr_topk_search_noalloc(q.data_ptr(), g.data_ptr(), 512, 20000, 512, 5, 0, s.data_ptr(), i.data_ptr(), st) == 0
     torch.cuda.synchronize(DEV)
+
+
+def test_noalloc_search_under_hip_graph_capture():
+    """The stated use of the entry point: after the Q = 0 set-up call, fr_topk_search_noalloc is captured into a
+    hipGraph (torch.cuda.graph: stream capture, where hipMalloc is not allowed) and replayed twice on new queries in
+    the same static buffer; each replay equals fr_topk_search on those queries bit for bit."""
+    lib = _lib.lib()
+    torch.cuda.set_device(DEV)
+    assert lib.fr_topk_search_noalloc(None, None, 0, 0, 512, 5, 0, None, None, None) == 0
+    Q, G, k = 700, 50_003, 5
+    g = fr.search.synth_rows(7, 0, G, DEV, plant_seed=11, n_plant=8, n_gallery_total=G)
+    q_static = fr.search.synth_rows(11, 0, Q, DEV)
+    s = torch.empty((Q, k), dtype=torch.float32, device=DEV)
+    i = torch.empty((Q, k), dtype=torch.int64, device=DEV)
+    torch.cuda.synchronize(DEV)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        st = torch.cuda.current_stream(DEV).cuda_stream
+        rc = lib.fr_topk_search_noalloc(q_static.data_ptr(), g.data_ptr(), Q, G, 512, k, 0, s.data_ptr(), i.data_ptr(), st)
+    assert rc == 0, lib.fr_last_error()
+    for seed in (13, 17):
+        q_new = fr.search.synth_rows(seed, 0, Q, DEV)
+        q_static.copy_(q_new)
+        s.fill_(float("nan")); i.fill_(-7)
+        graph.replay()
+        torch.cuda.synchronize(DEV)
+        s0, i0 = _search(False, q_new, g, k, 0)
+        assert torch.equal(i, i0) and torch.equal(s, s0)
