@@ -770,7 +770,8 @@ def test_file_entry_points_against_oracle(name, tmp_path, capsys):
     assert sorted(d) == sorted(names) and "broken.jpg" not in d
     assert "✗ Error processing broken.jpg" in printed and printed.count("✓ Processed") == len(names)
     assert f"Extracting embeddings from {len(names) + 1} images" in printed
-    marks = [ln.split(": ", 1)[1].split(":")[0] for ln in printed.splitlines() if ln[:1] in "✓✗"]
+    marks = [ln[len("✓ Processed: "):] if ln.startswith("✓") else ln[len("✗ Error processing "):].split(":")[0]
+             for ln in printed.splitlines() if ln.startswith(("✓ Processed: ", "✗ Error processing "))]
     assert [n for n in marks if n != "broken.jpg"] == list(d) and "broken.jpg" in marks
     order = [p_.name for ext in (".jpg", ".jpeg", ".png", ".bmp", ".tiff") for pat in (ext, ext.upper())
              for p_ in __import__("pathlib").Path(tmp_path).glob(f"*{pat}")]
