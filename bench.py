@@ -409,7 +409,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="mobilenetv3_large")
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "f24"],
                     help="mode of the headline value; bf16 is what BASELINE.json configs[1] names")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"],
                     help="f32: normalised fp32 NCHW tensors, the reference's model(tensor) contract (default); "

@@ -8,11 +8,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfr_hip.so")
 
-FR_PREC_BF16, FR_PREC_F32 = 0, 1
+FR_PREC_BF16, FR_PREC_F32, FR_PREC_F24 = 0, 1, 2
 FR_PLAN_NO_FUSE = 0x100
 FR_OP_CONV, FR_OP_SE, FR_OP_LINEAR = 0, 1, 2
 FR_ACT_NONE, FR_ACT_PRELU, FR_ACT_HSWISH, FR_ACT_RELU, FR_ACT_HSIGMOID = 0, 1, 2, 3, 4
-PRECISIONS = {"bf16": FR_PREC_BF16, "f32": FR_PREC_F32}
+PRECISIONS = {"bf16": FR_PREC_BF16, "f32": FR_PREC_F32, "f24": FR_PREC_F24}
 
 _fp = C.POINTER(C.c_float)
 

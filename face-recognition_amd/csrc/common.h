@@ -87,6 +87,86 @@ FR_DEV void store8(float* p, const Vec8f& x) {
     *reinterpret_cast<f32x4*>(p + 4) = b;
 }
 
+// ---- "f24" activation storage (FR_PREC_F24): the top 24 bits of the fp32 pattern (sign, 8 exponent bits, 15 stored
+// mantissa bits = 16 significant bits, what the split-bf16 GEMMs of the fp32 plans carry anyway), rounded to nearest, in
+// TWO PLANES: hi = the top 16 bits [M][C] -- a bf16 tensor (truncated, not rounded) in exactly the layout of the bf16
+// plans, and directly the hi operand of the split-bf16 MFMA products -- and lo = the next 8 bits as bytes
+// [M][f24_lo_pitch(C)] (rows padded to 16 B so that every row starts 16-byte aligned for LDS-DMA and vector stores).
+// 3 B per element instead of 4: the fp32 plans are byte-bound.  x - hi is exact in bf16 (8 bits).
+struct f24 {};
+template <typename T> struct act_hi { typedef T type; };
+template <> struct act_hi<f24> { typedef bf16 type; };
+template <typename T> constexpr bool kIsF24 = std::is_same<T, f24>::value;
+template <typename T> constexpr bool kWide = std::is_same<T, f24>::value || std::is_same<T, float>::value;   // fp32-class arithmetic (split operands)
+template <typename T> constexpr int kHiBytes = (int)sizeof(typename act_hi<T>::type);                         // bytes per element in the (hi) plane
+__host__ __device__ constexpr int f24_lo_pitch(int C) { return (C + 15) & ~15; }
+__host__ __device__ constexpr size_t f24_plane_bytes(size_t elems) { return elems * 2; }   // hi plane of a buffer; the lo plane follows it directly (elems % 8 == 0: 16-byte aligned)
+
+FR_DEV float f24_round(float v) { return __uint_as_float((__float_as_uint(v) + 0x80u) & 0xFFFFFF00u); }
+// 8 channels: hi = 4 dwords (8 x 16 bits), lo = 2 dwords (8 bytes)  ->  fp32 (exact)
+FR_DEV Vec8f f24_decode(const u32x4& hi, unsigned lo0, unsigned lo1) {
+    Vec8f o;
+    o.v[0] = __uint_as_float(__builtin_amdgcn_perm(hi[0], lo0, 0x0504000cu));
+    o.v[1] = __uint_as_float(__builtin_amdgcn_perm(hi[0], lo0, 0x0706010cu));
+    o.v[2] = __uint_as_float(__builtin_amdgcn_perm(hi[1], lo0, 0x0504020cu));
+    o.v[3] = __uint_as_float(__builtin_amdgcn_perm(hi[1], lo0, 0x0706030cu));
+    o.v[4] = __uint_as_float(__builtin_amdgcn_perm(hi[2], lo1, 0x0504000cu));
+    o.v[5] = __uint_as_float(__builtin_amdgcn_perm(hi[2], lo1, 0x0706010cu));
+    o.v[6] = __uint_as_float(__builtin_amdgcn_perm(hi[3], lo1, 0x0504020cu));
+    o.v[7] = __uint_as_float(__builtin_amdgcn_perm(hi[3], lo1, 0x0706030cu));
+    return o;
+}
+// fp32 -> rounded f24 planes of 8 channels
+FR_DEV void f24_encode(const Vec8f& x, u32x4& hi, unsigned& lo0, unsigned& lo1) {
+    unsigned u[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = __float_as_uint(x.v[i]) + 0x80u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hi[i] = __builtin_amdgcn_perm(u[2 * i + 1], u[2 * i], 0x07060302u);
+    lo0 = __builtin_amdgcn_perm(u[1], u[0], 0x0c0c0501u) | __builtin_amdgcn_perm(u[3], u[2], 0x05010c0cu);
+    lo1 = __builtin_amdgcn_perm(u[5], u[4], 0x0c0c0501u) | __builtin_amdgcn_perm(u[7], u[6], 0x05010c0cu);
+}
+// MFMA operands of 8 stored channels: hi fragment = the hi plane as it is, lo = x - hi (exact in bf16)
+FR_DEV void f24_frags(const u32x4& hi, unsigned lo0, unsigned lo1, bf16x8& fh, bf16x8& fl) {
+    const Vec8f x = f24_decode(hi, lo0, lo1);
+    u32x4 l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x.v[2 * i] - __uint_as_float(hi[i] << 16);
+        const float b = x.v[2 * i + 1] - __uint_as_float(hi[i] & 0xffff0000u);
+        l[i] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+    }
+    fh = __builtin_bit_cast(bf16x8, hi);
+    fl = __builtin_bit_cast(bf16x8, l);
+}
+// the same split from fp32 values that are ALREADY f24-rounded (fused kernels: a result that the unfused plan would
+// have stored and re-loaded): hi = truncation, lo = x - hi.  Bit-identical to f24_frags(f24_encode(x)).
+FR_DEV void f24_split8(const Vec8f& x, bf16x8& fh, bf16x8& fl) {
+    u32x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned u0 = __float_as_uint(x.v[2 * i]), u1 = __float_as_uint(x.v[2 * i + 1]);
+        h[i] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+        const float a = x.v[2 * i] - __uint_as_float(u0 & 0xffff0000u);
+        const float b = x.v[2 * i + 1] - __uint_as_float(u1 & 0xffff0000u);
+        l[i] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+    }
+    fh = __builtin_bit_cast(bf16x8, h);
+    fl = __builtin_bit_cast(bf16x8, l);
+}
+// global-memory forms: hi plane element pointer (bf16 layout) + lo plane byte pointer of the same 8 channels
+FR_DEV Vec8f f24_load8(const bf16* hi, const unsigned char* lo) {
+    const u32x4 h = *reinterpret_cast<const u32x4*>(hi);
+    const unsigned long long l = *reinterpret_cast<const unsigned long long*>(lo);
+    return f24_decode(h, (unsigned)l, (unsigned)(l >> 32));
+}
+FR_DEV void f24_store8(bf16* hi, unsigned char* lo, const Vec8f& x) {
+    u32x4 h; unsigned l0, l1;
+    f24_encode(x, h, l0, l1);
+    *reinterpret_cast<u32x4*>(hi) = h;
+    *reinterpret_cast<unsigned long long*>(lo) = (unsigned long long)l0 | ((unsigned long long)l1 << 32);
+}
+
 FR_DEV float apply_act(float v, int act, float slope) {
     switch (act) {
         case FR_ACT_PRELU:    return v >= 0.f ? v : v * slope;
@@ -222,6 +302,9 @@ struct EpiArgs {
     void* y;                // [M, cout] activation-typed
     int cout;
     int act;
+    // f24 plans: the lo planes ([M][f24_lo_pitch(cout)] bytes) of y and of the residual
+    unsigned char* y_lo;
+    const unsigned char* residual_lo;
 };
 
 // Store one 32x32 accumulator tile.  Lane: pixel m (row of Y), channels c0 .. c0+15.
@@ -243,12 +326,22 @@ FR_DEV void epilogue_store(const f32x16& acc, const EpiArgs& e, long m, int c0, 
             act8(v, e.act, nullptr);
         }
         long off = m * (long)e.cout + c;
-        if (e.residual) {
-            Vec8f r = load8(reinterpret_cast<const TOut*>(e.residual) + off);
+        if constexpr (kIsF24<TOut>) {
+            const long off_lo = m * (long)f24_lo_pitch(e.cout) + c;
+            if (e.residual) {
+                Vec8f r = f24_load8(reinterpret_cast<const bf16*>(e.residual) + off, e.residual_lo + off_lo);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
+                for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
+            }
+            f24_store8(reinterpret_cast<bf16*>(e.y) + off, e.y_lo + off_lo, v);
+        } else {
+            if (e.residual) {
+                Vec8f r = load8(reinterpret_cast<const TOut*>(e.residual) + off);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
+            }
+            store8(reinterpret_cast<TOut*>(e.y) + off, v);
         }
-        store8(reinterpret_cast<TOut*>(e.y) + off, v);
     }
 }
 
@@ -305,4 +398,54 @@ FR_DEV void epilogue_stage_f32(const f32x16& acc, const EpiArgs& e, long m, int 
         }
         stage_put_f32(stage, pitch, row, col0 + 8 * g, v);
     }
+}
+
+// epilogue_stage for f24 outputs: same arithmetic, the result rounded to f24; the hi halves go to the wave's bf16-shaped
+// staging tile (written back by stage_flush like a bf16 tile), the lo bytes of the lane's 16 channels (16 B) to a second
+// tile at byte column col0 (written back by stage_flush_lo).  A lane whose pixel is out of range writes nothing.
+FR_DEV void epilogue_stage_f24(const f32x16& acc, const EpiArgs& e, long m, int c0, bool m_ok,
+                               unsigned char* stage, int pitch, unsigned char* stage_lo, int pitch_lo, int row, int col0) {
+    if (!m_ok) return;
+    u32x4 lo = {0u, 0u, 0u, 0u};
+    const int LP = f24_lo_pitch(e.cout);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        int c = c0 + 8 * g;
+        if (c >= e.cout) continue;
+        Vec8f v;
+        f32x4 b0 = *reinterpret_cast<const f32x4*>(e.bias + c);
+        f32x4 b1 = *reinterpret_cast<const f32x4*>(e.bias + c + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v.v[i] = acc[8 * g + i] + b0[i]; v.v[4 + i] = acc[8 * g + 4 + i] + b1[i]; }
+        if (e.act == FR_ACT_PRELU) {
+            prelu8(v, *reinterpret_cast<const f32x4*>(e.slope + c), *reinterpret_cast<const f32x4*>(e.slope + c + 4));
+        } else if (e.act != FR_ACT_NONE) {
+            act8(v, e.act, nullptr);
+        }
+        if (e.residual) {
+            Vec8f r = f24_load8(reinterpret_cast<const bf16*>(e.residual) + m * (long)e.cout + c, e.residual_lo + m * (long)LP + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
+        }
+        u32x4 h; unsigned l0, l1;
+        f24_encode(v, h, l0, l1);
+        *reinterpret_cast<u32x4*>(stage + row * pitch + (col0 + 8 * g) * 2) = h;
+        lo[2 * g] = l0; lo[2 * g + 1] = l1;
+    }
+    *reinterpret_cast<u32x4*>(stage_lo + row * pitch_lo + col0) = lo;
+}
+// rows [0,rows) x ncol channels of the lo staging tile -> the lo plane (row stride lp bytes), whole 16-byte chunks (a
+// trailing half chunk lands in the padding of the 16-byte-padded lo rows)
+__host__ __device__ constexpr int stage_pitch_lo(int row_bytes) { return row_bytes + 16; }
+FR_DEV void stage_flush_lo(const unsigned char* stage_lo, int pitch_lo, int lane, unsigned char* y_lo, long lp, int ncol, int rows) {
+    const int cr = (ncol + 15) >> 4;                            // 16-byte chunks per row (<= 8)
+    const unsigned magic = (65536u + cr - 1) / cr;
+    const int total = rows * cr;
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < total; c += 64) {
+        const int row = (int)(((unsigned)c * magic) >> 16), ch = c - row * cr;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage_lo + row * pitch_lo + ch * 16);
+        *reinterpret_cast<u32x4*>(y_lo + row * lp + ch * 16) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
 }

@@ -24,11 +24,14 @@ typedef const __attribute__((address_space(1))) void* dw_glb_ptr_t;
 struct Div32 { unsigned mul, d; };
 static inline Div32 make_div32(unsigned d) { Div32 r; r.d = d; r.mul = d > 1 ? (unsigned)((1ull << 32) / d + 1ull) : 0u; return r; }
 FR_DEV unsigned div32(unsigned n, Div32 v) { return v.d == 1 ? n : __umulhi(n, v.mul); }
+FR_DEV Div32 make_div32_dev(unsigned d) { Div32 r; r.d = d; r.mul = d > 1 ? (unsigned)((1ull << 32) / d + 1ull) : 0u; return r; }
 
 struct DwGeom {          // derived launch geometry (host computed)
     Div32 d_cbv, d_iw, d_ns, d_tw;
     int IH, IW, nstrips, nitems, nunits;
     int PP;              // LDS pitch of one tile pixel in 8-channel vectors (CBV, or CBV+1 when the tile is computed in the kernel)
+    int PPL;             // f24 tiles staged from HBM: 16-byte slots per pixel of the lo part (two channel vectors per slot)
+    int tile_bytes;      // LDS bytes of the input tile (taps, bias and slopes follow it)
     int n0;              // first image of this launch slice (blockIdx.z is relative to it)
     // XCD-aware block order (dw_block): images in groups of 8, one image per XCD
     Div32 d_per8, d_gx;
@@ -67,11 +70,12 @@ template <int S> __host__ __device__ constexpr int dw_sw() { return S == 2 ? 2 :
 // weights [K*K][2][CBV][4] fp32, then bias [2][CBV][4], then slopes [2][CBV][4].
 template <typename T, int K, int S, bool TILE = true>
 FR_DEV void dw_stage(const DwArgs& a, const DwGeom& g, unsigned char* smem, int n, int cc, int ty, int tx) {
-    constexpr int UPE = sizeof(V8<T>) / 16;         // 16-byte units per 8-channel vector
+    constexpr int UPE = std::is_same<T, float>::value ? 2 : 1;     // 16-byte units per 8-channel vector (f24: of its hi part)
+    constexpr int EB = kHiBytes<T>;
     const int CBV = a.CBV, CV = a.C >> 3, IW = g.IW;
     const int cv0 = cc * CBV, ncv = min(CBV, CV - cv0);
-    unsigned char* wl_b = smem + (size_t)g.IH * IW * g.PP * sizeof(V8<T>);
-    const unsigned char* Xn = reinterpret_cast<const unsigned char*>(a.x) + (size_t)n * a.H * a.W * a.C * sizeof(T);
+    unsigned char* wl_b = smem + g.tile_bytes;
+    const unsigned char* Xn = reinterpret_cast<const unsigned char*>(a.x) + (size_t)n * a.H * a.W * a.C * EB;
     const unsigned char* Z = reinterpret_cast<const unsigned char*>(a.zeros);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int gy0 = ty * a.TH * S - a.pad, gx0 = tx * a.TW * S - a.pad;
@@ -86,9 +90,28 @@ FR_DEV void dw_stage(const DwArgs& a, const DwGeom& g, unsigned char* smem, int 
             const unsigned iy = div32(pix, g.d_iw), ix = pix - iy * IW;
             const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
             const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && (int)cv < ncv;
-            const int off = ((gy * a.W + gx) * a.C + (cv0 + (int)cv) * 8) * (int)sizeof(T) + (int)half * 16;
+            const int off = ((gy * a.W + gx) * a.C + (cv0 + (int)cv) * 8) * EB + (int)half * 16;
             const unsigned char* src = ok ? Xn + off : Z;
             __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + u0 * 16), 16, 0, 0);
+        }
+    }
+    if constexpr (kIsF24<T>) {
+        // lo bytes: unit (pixel, j) = the 16 lo bytes of channel vectors 2j, 2j+1 of the chunk (cv0 is even; lo rows are
+        // padded to 16 B, so a trailing half unit reads padding); behind the hi part of the tile
+        const int PPL = g.PPL, nlo = g.IH * IW * PPL, LP = f24_lo_pitch(a.C);
+        const unsigned char* XLn = a.x_lo + (size_t)n * a.H * a.W * LP;
+        unsigned char* lo_b = smem + (size_t)g.IH * IW * g.PP * 16;
+        const Div32 d_ppl = make_div32_dev(PPL);
+        for (int u0 = wave * 64; TILE && u0 < nlo; u0 += 256) {
+            const int u = u0 + lane;
+            if (u < nlo) {
+                const unsigned pix = div32(u, d_ppl), j = u - pix * PPL;
+                const unsigned iy = div32(pix, g.d_iw), ix = pix - iy * IW;
+                const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
+                const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && (int)(2 * j) < ncv;
+                const unsigned char* src = ok ? XLn + (gy * a.W + gx) * LP + (cv0 + 2 * (int)j) * 8 : Z;
+                __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(lo_b + u0 * 16), 16, 0, 0);
+            }
         }
     }
     // tap weights, unit (tap, half, cv) = 4 floats w[tap][(cv0+cv)*8 + 4*half ..]
@@ -116,9 +139,12 @@ FR_DEV void dw_stage(const DwArgs& a, const DwGeom& g, unsigned char* smem, int 
 
 // One work item: SW horizontally adjacent outputs (row oy, strip sx of the tile) x channel vector cv,
 // bias included, activation applied.  out[o] = activated fp32 outputs.
-template <typename T, int K, int S>
-FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const float* bl, int IW, int PP,
-                    unsigned cv, unsigned oy, unsigned sx, Vec8f (&out)[dw_sw<S>()]) {
+// T: format of the LDS tile -- bf16 vectors, fp32 half-planes, or f24 as staged from HBM (hi part [pixel][PP] 16-byte
+// slots, lo part `tile_lo` [pixel][PPL] 16-byte slots of two vectors each).  R24: the activated result is rounded to f24
+// (f24 plans: it is stored as f24, or handed to the fused 1x1 conv as the unfused plan would re-load it).
+template <typename T, int K, int S, bool R24 = false>
+FR_DEV void dw_item(const DwArgs& a, const void* tile, const float* wl, const float* bl, int IW, int PP,
+                    unsigned cv, unsigned oy, unsigned sx, Vec8f (&out)[dw_sw<S>()], const unsigned char* tile_lo = nullptr, int PPL = 0) {
     constexpr int SW = dw_sw<S>();
     constexpr int IWS = (SW - 1) * S + K;
     const int CBV = a.CBV;
@@ -132,8 +158,10 @@ FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const f
             for (int j = 0; j < 4; ++j) { acc[o][j] = b0[j]; acc[o][4 + j] = b1[j]; }
     }
     // 16-byte slots: bf16 (pixel * PP + cv); fp32 ((pixel * 2 + half) * PP + cv), see dw_stage
-    constexpr int HP = sizeof(T) == 4 ? 2 : 1;
+    constexpr int HP = std::is_same<T, float>::value ? 2 : 1;
     const unsigned char* row = reinterpret_cast<const unsigned char*>(tile) + ((((oy * S) * IW + sx * SW * S) * HP) * PP + cv) * 16;
+    const unsigned char* rowl = kIsF24<T> ? tile_lo + ((oy * S) * IW + sx * SW * S) * PPL * 16 + cv * 8 : nullptr;
+    (void)rowl;
     const float* wrow = wl + cv * 4;
 #pragma unroll 1
     for (int ky = 0; ky < K; ++ky) {
@@ -152,8 +180,12 @@ FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const f
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(row + (ix * 2) * PP * 16), v1 = *reinterpret_cast<const f32x4*>(row + (ix * 2 + 1) * PP * 16);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v.v[j] = v0[j]; v.v[4 + j] = v1[j]; }
+            } else if constexpr (kIsF24<T>) {
+                const u32x4 hh = *reinterpret_cast<const u32x4*>(row + ix * PP * 16);
+                const unsigned long long ll = *reinterpret_cast<const unsigned long long*>(rowl + ix * PPL * 16);
+                v = f24_decode(hh, (unsigned)ll, (unsigned)(ll >> 32));
             } else {
-                v = load8(reinterpret_cast<const T*>(row + ix * PP * 16));
+                v = load8(reinterpret_cast<const bf16*>(row + ix * PP * 16));
             }
 #pragma unroll
             for (int o = 0; o < SW; ++o) {
@@ -165,6 +197,7 @@ FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const f
             }
         }
         row += IW * HP * PP * 16;
+        if constexpr (kIsF24<T>) rowl += IW * PPL * 16;
         wrow += K * 2 * CBV * 4;
     }
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
@@ -178,6 +211,10 @@ FR_DEV void dw_item(const DwArgs& a, const V8<T>* tile, const float* wl, const f
         for (int j = 0; j < 8; ++j) out[o].v[j] = acc[o][j];
         if (a.act == FR_ACT_PRELU) prelu8(out[o], s0, s1);
         else act8(out[o], a.act, nullptr);
+        if constexpr (R24) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[o].v[j] = f24_round(out[o].v[j]);
+        }
     }
 }
 
@@ -193,10 +230,15 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int IW = g.IW;
 
-    const V8<T>* tile = reinterpret_cast<const V8<T>*>(smem);            // [IH*IW][CBV]
-    const float* wl = reinterpret_cast<const float*>(smem + (size_t)g.IH * IW * g.PP * sizeof(V8<T>));
+    const void* tile = smem;                                             // [IH*IW][CBV]
+    const unsigned char* tile_lo = smem + (size_t)g.IH * IW * g.PP * 16; // f24 only
+    const float* wl = reinterpret_cast<const float*>(smem + g.tile_bytes);
     const float* bl = wl + K * K * CBV * 8;
-    unsigned char* Yn = reinterpret_cast<unsigned char*>(a.y) + (size_t)n * a.Ho * a.Wo * a.C * sizeof(T);
+    constexpr int EB = kHiBytes<T>;
+    unsigned char* Yn = reinterpret_cast<unsigned char*>(a.y) + (size_t)n * a.Ho * a.Wo * a.C * EB;
+    const int LPo = f24_lo_pitch(a.C);
+    unsigned char* YLn = kIsF24<T> ? a.y_lo + (size_t)n * a.Ho * a.Wo * LPo : nullptr;
+    (void)YLn;
     dw_stage<T, K, S>(a, g, smem, n, cc, ty, tx);
 
     // psum receives the sum of the valid outputs (squeeze-excite pooling) when a.pool is set
@@ -205,11 +247,11 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
         const unsigned oy = div32(r, g.d_ns), sx = r - oy * g.nstrips;
         if ((int)cv >= ncv) return;
         Vec8f out[SW];
-        dw_item<T, K, S>(a, tile, wl, bl, IW, g.PP, cv, oy, sx, out);
+        dw_item<T, K, S, kIsF24<T>>(a, tile, wl, bl, IW, g.PP, cv, oy, sx, out, tile_lo, g.PPL);
         const int gy = oy0 + (int)oy;
         if (gy < a.Ho) {
             const int gx0o = ox0 + (int)sx * SW;
-            const int yoff = ((gy * a.Wo + gx0o) * a.C + (cv0 + (int)cv) * 8) * (int)sizeof(T);
+            const int yoff = ((gy * a.Wo + gx0o) * a.C + (cv0 + (int)cv) * 8) * EB;
 #pragma unroll
             for (int o = 0; o < SW; ++o) {
                 if (gx0o + o < a.Wo) {
@@ -217,7 +259,9 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) psum[j] += out[o].v[j];
                     }
-                    store8(reinterpret_cast<T*>(Yn + yoff + o * a.C * (int)sizeof(T)), out[o]);
+                    if constexpr (kIsF24<T>)
+                        f24_store8(reinterpret_cast<bf16*>(Yn + yoff + o * a.C * EB), YLn + (gy * a.Wo + gx0o + o) * LPo + (cv0 + (int)cv) * 8, out[o]);
+                    else store8(reinterpret_cast<T*>(Yn + yoff + o * a.C * EB), out[o]);
                 }
             }
         }
@@ -252,9 +296,13 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
     }
 }
 
-static size_t dw_lds_bytes(bool f32, int k, int s, int TH, int TW, int CBV) {
+static size_t dw_tile_bytes(int fmt, int IH, int IW, int PP) {      // input tile as staged from HBM
+    if (fmt == FMT_F24) return (size_t)IH * IW * (PP + (PP + 1) / 2) * 16;
+    return (size_t)IH * IW * PP * (fmt == FMT_F32 ? 32 : 16);
+}
+static size_t dw_lds_bytes(int fmt, int k, int s, int TH, int TW, int CBV) {
     const int IH = (TH - 1) * s + k, IW = (TW - 1) * s + k;
-    return (size_t)IH * IW * CBV * (f32 ? 32 : 16) + (size_t)k * k * CBV * 32 + (size_t)CBV * 64;
+    return dw_tile_bytes(fmt, IH, IW, CBV) + (size_t)k * k * CBV * 32 + (size_t)CBV * 64;
 }
 
 // Pick the output tile and channel chunk: keep LDS <= 40 KB (>= 3 blocks per CU), prefer all
@@ -273,17 +321,22 @@ static const DwTileEntry kDwTilesF32[] = {        // fp32 plans (tools/dw_probe.
 #include "dw_tiles_f32.inc"
 };
 
-static void dw_pick_tile(bool f32, int k, int s, DwArgs& a) {
+static void dw_pick_tile(int fmt, int k, int s, DwArgs& a) {
     const int CV = a.C / 8;
     const int sw = s == 2 ? 2 : 4;
     static const bool use_table = !(getenv("FR_DW_TABLE") && atoi(getenv("FR_DW_TABLE")) == 0);     // 0: cost model only (tools/dw_probe.py measures against it)
-    if (a.Ho == a.Wo && use_table) {
-        const DwTileEntry* tb = f32 ? kDwTilesF32 : kDwTiles;
-        const size_t ne = f32 ? sizeof(kDwTilesF32) / sizeof(DwTileEntry) : sizeof(kDwTiles) / sizeof(DwTileEntry);
+    // f24 tiles take 24 B per channel vector: the bf16 winners where they still fit, else the fp32 ones.  A channel chunk
+    // must start on an even vector (the lo part is staged in 16-byte units of two vectors).
+    for (int pass = 0; pass < 2 && a.Ho == a.Wo && use_table; ++pass) {
+        const bool f32tab = fmt == FMT_F32 || (fmt == FMT_F24 && pass == 1);
+        if (pass == 1 && fmt != FMT_F24) break;
+        const DwTileEntry* tb = f32tab ? kDwTilesF32 : kDwTiles;
+        const size_t ne = f32tab ? sizeof(kDwTilesF32) / sizeof(DwTileEntry) : sizeof(kDwTiles) / sizeof(DwTileEntry);
         for (size_t i = 0; i < ne; ++i) {
             const DwTileEntry& e = tb[i];
             if (e.C == a.C && e.Ho == a.Ho && e.k == k && e.s == s && e.TW % sw == 0 && e.CBV <= CV &&
-                e.TH * (e.TW / sw) * e.CBV <= 512 && dw_lds_bytes(f32, k, s, e.TH, e.TW, e.CBV) <= 60 * 1024) {
+                (fmt != FMT_F24 || e.CBV % 2 == 0 || e.CBV >= CV) &&
+                e.TH * (e.TW / sw) * e.CBV <= 512 && dw_lds_bytes(fmt, k, s, e.TH, e.TW, e.CBV) <= 60 * 1024) {
                 a.TH = e.TH; a.TW = e.TW; a.CBV = e.CBV;
                 a.tiles_y = cdiv(a.Ho, e.TH); a.tiles_x = cdiv(a.Wo, e.TW); a.cchunks = cdiv(CV, e.CBV);
                 return;
@@ -297,7 +350,9 @@ static void dw_pick_tile(bool f32, int k, int s, DwArgs& a) {
         if (th > a.Ho && th != ths[0]) { if (th - a.Ho >= 2) continue; }
         if (tw - a.Wo >= 4) continue;
         for (int cbv = std::min(CV, 16); cbv >= 1; cbv = (cbv > 1 ? (cbv + 1) / 2 : 0)) {
-            if (dw_lds_bytes(f32, k, s, th, tw, cbv) > 40 * 1024) continue;
+            if (fmt == FMT_F24 && cbv < CV && (cbv & 1)) { if (cbv > 1) ++cbv; else continue; }     // even chunks (see above); the loop halves it again
+            if (fmt == FMT_F24 && cbv > 16) continue;
+            if (dw_lds_bytes(fmt, k, s, th, tw, cbv) > 40 * 1024) continue;
             const int tyc = cdiv(a.Ho, th), txc = cdiv(a.Wo, tw), ccs = cdiv(CV, cbv);
             const int items = th * (tw / sw) * cbv;
             if (items > 512) continue;                      // two passes at most (the pooled form keeps per-pass sums in registers)
@@ -327,20 +382,22 @@ static int launch_dw_t(int k, int s, const DwArgs& a, DwGeom g, size_t lds, hipS
     return FR_OK;
 }
 
-int dw_tiles_per_image(bool f32, int k, int stride, int C, int Ho, int Wo) {
+int dw_tiles_per_image(int fmt, int k, int stride, int C, int Ho, int Wo) {
     DwArgs a{};
     a.C = C; a.Ho = Ho; a.Wo = Wo; a.TH = 0;
-    dw_pick_tile(f32, k, stride, a);
+    dw_pick_tile(fmt, k, stride, a);
     return a.TH ? a.tiles_y * a.tiles_x : 0;
 }
 
-int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st) {
+int launch_dw(int fmt, int k, int stride, DwArgs a, hipStream_t st) {
+    const bool f32 = fmt == FMT_F32;
+    if (fmt == FMT_F24 && (!a.x_lo || !a.y_lo)) FR_FAIL(FR_ERR_ARG, "depthwise: f24 tensors without their lo planes");
     if (a.C % 8 || a.N <= 0) FR_FAIL(FR_ERR_ARG, "depthwise: C must be a multiple of 8");
     if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: only k in {3,5}, stride in {1,2}");
     if (!a.zeros) FR_FAIL(FR_ERR_ARG, "depthwise: no zero page");
     if ((long)a.H * a.W * a.C * 4 >= 0x7FFFFFFFL) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: image above 2 GB");
     a.TH = 0;
-    dw_pick_tile(f32, k, stride, a);
+    dw_pick_tile(fmt, k, stride, a);
     if (a.TH == 0) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: no tile fits LDS");
     if (const char* ov = getenv("FR_DW_TILE")) {           // tuning override: "C,Ho,k,s,TH,TW,CBV" for the matching layers
         int c, ho, kk, ss, th, tw, cbv;
@@ -350,9 +407,10 @@ int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st) {
             a.tiles_y = cdiv(a.Ho, th); a.tiles_x = cdiv(a.Wo, tw); a.cchunks = cdiv(a.C / 8, a.CBV);
         }
     }
+    if (fmt == FMT_F24 && a.cchunks > 1 && (a.CBV & 1)) FR_FAIL(FR_ERR_ARG, "depthwise (f24): channel chunks must hold an even number of 8-channel vectors");
     if (a.CBV > 16) FR_FAIL(FR_ERR_ARG, "depthwise: channel chunk above 128 channels");
     if (a.tiles_y > 65535 || (long)a.tiles_x * a.cchunks > 0x7FFFFFFFL) FR_FAIL(FR_ERR_ARG, "depthwise: grid too large");
-    const size_t lds = dw_lds_bytes(f32, k, stride, a.TH, a.TW, a.CBV);
+    const size_t lds = dw_lds_bytes(fmt, k, stride, a.TH, a.TW, a.CBV);
     if (lds > 64 * 1024) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: tile above 64 KB of LDS");
     if (a.pool && a.pool_tiles != a.tiles_y * a.tiles_x) FR_FAIL(FR_ERR_ARG, "depthwise: pool buffer sized for another tiling");
     DwGeom g{};
@@ -362,8 +420,12 @@ int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st) {
     g.nitems = a.TH * g.nstrips * a.CBV;
     g.nunits = g.IH * g.IW * a.CBV * (f32 ? 2 : 1);
     g.PP = a.CBV;
+    g.PPL = (a.CBV + 1) / 2;
+    g.tile_bytes = (int)dw_tile_bytes(fmt, g.IH, g.IW, g.PP);
     g.d_cbv = make_div32(a.CBV); g.d_iw = make_div32(g.IW); g.d_ns = make_div32(g.nstrips);
     if (a.pool && g.nitems > 512) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: pooled form needs <= 512 work items per tile");
+    if (a.pool && (size_t)g.nitems * 32 > (size_t)g.tile_bytes) FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: pooled sums do not fit the input tile");
+    if (fmt == FMT_F24) return launch_dw_t<f24>(k, stride, a, g, lds, st);
     return f32 ? launch_dw_t<float>(k, stride, a, g, lds, st) : launch_dw_t<bf16>(k, stride, a, g, lds, st);
 }
 
@@ -390,6 +452,7 @@ struct DwpArgs {
     int off_pb;           // bias then slopes of the 1x1 conv, [NT*32] floats each
     // optional expand 1x1 conv in front (EXPAND form): dw.x is then unused
     const void* xin;      // block input [N,H,W,Cin]
+    const unsigned char* xin_lo;   // f24: its lo plane
     const bf16* we;       // expand weights packed [NTe][KSe][NS][64][8]
     const float* be;      // expand bias (padded to 32)
     const float* se;      // expand PReLU slopes or NULL
@@ -406,13 +469,17 @@ struct DwpArgs {
 template <typename T, int KSE, int NTE, int ACT, bool MASK>
 FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, const float* bel, const float* sel,
                        int gy0, int gx0, int wave, int lane) {
-    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr bool F32 = kWide<T>;                    // fp32-class arithmetic; the expanded tile is fp32 half-planes
+    constexpr bool F24 = kIsF24<T>;
     constexpr int NS = F32 ? 2 : 1;
     const DwArgs& a = x.dw;
     const int IW = g.IW, npin = g.IH * IW;
     const int pe = lane & 31, he = lane >> 5;
     const unsigned char* inl = smem + x.off_in;
-    const int rowb = x.Cin * (int)sizeof(T);
+    const int rowb = x.Cin * kHiBytes<T>;
+    const int LPin = f24_lo_pitch(x.Cin);
+    const unsigned char* inl_lo = inl + (size_t)npin * rowb;          // f24: staged lo rows [pixel][LPin]
+    (void)LPin; (void)inl_lo;
     bf16x8 wv[NTE][KSE][NS];
     f32x4 bb[NTE][4], ss[NTE][4];                     // bias and (PReLU) slopes of this lane's 16 channels per tile
     {
@@ -443,7 +510,13 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
 #pragma unroll
         for (int sk = 0; sk < KSE; ++sk) {
             const int kk = 16 * sk + 8 * he;
-            if constexpr (F32) {
+            if constexpr (F24) {
+                if (kk < x.Cin) {
+                    const u32x4 hh = *reinterpret_cast<const u32x4*>(inl + pc * rowb + kk * 2);
+                    const unsigned long long ll = *reinterpret_cast<const unsigned long long*>(inl_lo + pc * LPin + kk);
+                    f24_frags(hh, (unsigned)ll, (unsigned)(ll >> 32), xf[sk][0], xf[sk][1]);
+                } else { xf[sk][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xf[sk][1] = xf[sk][0]; }
+            } else if constexpr (F32) {
                 if (kk < x.Cin) split8(load8(reinterpret_cast<const float*>(inl + pc * rowb) + kk), xf[sk][0], xf[sk][1]);
                 else { xf[sk][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xf[sk][1] = xf[sk][0]; }
             } else {
@@ -496,6 +569,10 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
                 }
                 const bool live = pix < npin && (t < NTE - 1 || c < a.C);
                 if constexpr (F32) {
+                    if constexpr (F24) {                 // what the unfused plan stores and re-loads
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v.v[i] = f24_round(v.v[i]);
+                    }
                     f32x4 r0, r1;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { r0[i] = (!MASK || inimg) ? v.v[i] : 0.f; r1[i] = (!MASK || inimg) ? v.v[4 + i] : 0.f; }
@@ -521,9 +598,12 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
 template <typename T, int K, int S, int KSE, int NTE>
 __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     constexpr bool EXPAND = KSE > 0;      // KSE, NTE: k-steps and 32-channel tiles of the expand conv (compile time)
-    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr bool F32 = kWide<T>;        // fp32-class arithmetic (fp32 or f24 activations): split operands, hi + lo planes
+    constexpr bool F24 = kIsF24<T>;
     constexpr int NS = F32 ? 2 : 1;
-    constexpr int UPE = sizeof(V8<T>) / 16;
+    constexpr int UPE = std::is_same<T, float>::value ? 2 : 1;     // 16-byte units of 8 channels in HBM (f24: of the hi plane)
+    constexpr int EB = kHiBytes<T>;
+    typedef typename std::conditional<EXPAND && F32, float, T>::type TT;    // format of the depthwise tile in LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SW = dw_sw<S>();
     const DwArgs& a = x.dw;
@@ -549,8 +629,9 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
             __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + x.off_pb), 16, 0, 0);
         }
     }
-    const V8<T>* tile = reinterpret_cast<const V8<T>*>(smem);
-    const float* wl = reinterpret_cast<const float*>(smem + (size_t)g.IH * IW * g.PP * sizeof(V8<T>));
+    const void* tile = smem;
+    const unsigned char* tile_lo = smem + (size_t)g.IH * IW * g.PP * 16;     // f24 tile staged from HBM only
+    const float* wl = reinterpret_cast<const float*>(smem + g.tile_bytes);
     const float* bl = wl + K * K * CBV * 8;
     if constexpr (!EXPAND) {
         dw_stage<T, K, S>(a, g, smem, n, 0, ty, tx);
@@ -560,20 +641,38 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
         // pixels outside the image are zero (the padding of the depthwise conv), not act(bias)
         const int cin8 = x.Cin >> 3, npin = g.IH * IW;
         const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;
-        const unsigned char* Xn = reinterpret_cast<const unsigned char*>(x.xin) + (size_t)n * a.H * a.W * x.Cin * sizeof(T);
+        const unsigned char* Xn = reinterpret_cast<const unsigned char*>(x.xin) + (size_t)n * a.H * a.W * x.Cin * EB;
         const unsigned char* Z = reinterpret_cast<const unsigned char*>(a.zeros);
-        const int nin = npin * cin8 * UPE;              // 16-byte units
-        for (int u0 = wave * 64; u0 < nin; u0 += 256) {
+        const int nin_hi = npin * cin8 * UPE;           // 16-byte units
+        for (int u0 = wave * 64; u0 < nin_hi; u0 += 256) {
             const int u = u0 + lane;
-            if (u < nin) {
+            if (u < nin_hi) {
                 const unsigned q = (unsigned)u / UPE;
                 const unsigned pix = div32(q, x.d_cin8), cv = q - pix * cin8;
                 const unsigned iy = div32(pix, g.d_iw), ix = pix - iy * IW;
                 const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
                 const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-                const unsigned char* src = ok ? Xn + ((gy * a.W + gx) * x.Cin + (int)cv * 8) * (int)sizeof(T) + (u % UPE) * 16 : Z;
+                const unsigned char* src = ok ? Xn + ((gy * a.W + gx) * x.Cin + (int)cv * 8) * EB + (u % UPE) * 16 : Z;
                 __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + x.off_in + u0 * 16), 16, 0, 0);
             }
+        }
+        int nin = nin_hi;
+        if constexpr (F24) {                            // the lo rows of the same pixels, [pixel][LPin], behind the hi rows
+            const int LPin = f24_lo_pitch(x.Cin), upp = LPin >> 4, nlo = npin * upp;
+            const unsigned char* XLn = x.xin_lo + (size_t)n * a.H * a.W * LPin;
+            const Div32 d_upp = make_div32_dev(upp);
+            for (int u0 = wave * 64; u0 < nlo; u0 += 256) {
+                const int u = u0 + lane;
+                if (u < nlo) {
+                    const unsigned pix = div32(u, d_upp), j = u - pix * upp;
+                    const unsigned iy = div32(pix, g.d_iw), ix = pix - iy * IW;
+                    const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
+                    const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                    const unsigned char* src = ok ? XLn + (gy * a.W + gx) * LPin + (int)j * 16 : Z;
+                    __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + x.off_in + (nin_hi + u0) * 16), 16, 0, 0);
+                }
+            }
+            nin += nlo;
         }
         for (int f = wave; f < NTE * KSE * NS; f += 4)
             __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)(reinterpret_cast<const u32x4*>(x.we) + f * 64 + lane),
@@ -616,12 +715,13 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
             const unsigned r = div32(it, g.d_cbv), cv = it - r * CBV;
             const unsigned oy = div32(r, g.d_ns), sx = r - oy * g.nstrips;
             Vec8f out[SW];
-            dw_item<T, K, S>(a, tile, wl, bl, IW, g.PP, cv, oy, sx, out);
+            dw_item<TT, K, S, F24>(a, tile, wl, bl, IW, g.PP, cv, oy, sx, out, tile_lo, g.PPL);
 #pragma unroll
             for (int o = 0; o < SW; ++o) {
                 if constexpr (F32) {
                     bf16x8 hi, lo;
-                    split8(out[o], hi, lo);
+                    if constexpr (F24) f24_split8(out[o], hi, lo);
+                    else split8(out[o], hi, lo);
                     keep[ps][o][0] = __builtin_bit_cast(u32x4, hi);
                     keep[ps][o][1] = __builtin_bit_cast(u32x4, lo);
                 } else {
@@ -648,8 +748,12 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     // 1x1 conv on MFMA: D[cout][pixel] = W . dwo^T, 32 pixels per wave step
     const int p = lane & 31, h = lane >> 5;
     constexpr int SG = 2;
-    constexpr int PITCH = stage_pitch(SG * 32 * (int)sizeof(T));
+    constexpr int PITCH = stage_pitch(SG * 32 * EB);
+    constexpr int PITCH_LO = stage_pitch_lo(SG * 32);
     unsigned char* stage = smem + x.off_stage + wave * 32 * PITCH;
+    unsigned char* stage_lo = smem + x.off_stage + 4 * 32 * PITCH + wave * 32 * PITCH_LO;     // f24 only
+    (void)stage_lo;
+    const int LPo = f24_lo_pitch(x.e.cout);
     const bf16x8* wf = reinterpret_cast<const bf16x8*>(smem + x.off_wp) + lane;
     EpiArgs e2 = x.e;
     e2.bias = reinterpret_cast<const float*>(smem + x.off_pb);
@@ -686,12 +790,13 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
                             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[(s * NS + 1) * 64], xf, acc, 0, 0, 0);
                         }
                     }
-                    if constexpr (F32) epilogue_stage_f32(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, p, 32 * tt + 16 * h);
+                    if constexpr (F24) epilogue_stage_f24(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, stage_lo, PITCH_LO, p, 32 * tt + 16 * h);
+                    else if constexpr (F32) epilogue_stage_f32(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, p, 32 * tt + 16 * h);
                     else epilogue_stage(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, p, 32 * tt + 16 * h);
                 }
             }
             // write the staged [32 pixels][<= 64 channels] back: consecutive pixels of a tile row are contiguous
-            const int ncol = min(SG * 32, cout - tg * 32), cr = (ncol * (int)sizeof(T)) >> 4;
+            const int ncol = min(SG * 32, cout - tg * 32), cr = (ncol * EB) >> 4;
             const unsigned magic = (65536u + cr - 1) / cr;
             __builtin_amdgcn_wave_barrier();
             for (int c = lane; c < 32 * cr; c += 64) {
@@ -702,7 +807,21 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
                 if (qpx < x.npx && y < a.Ho && xx < a.Wo) {
                     const u32x4 v = *reinterpret_cast<const u32x4*>(stage + q * PITCH + ch * 16);
                     *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(x.e.y) +
-                                              ((((long)n * a.Ho + y) * a.Wo + xx) * cout + tg * 32) * (long)sizeof(T) + ch * 16) = v;
+                                              ((((long)n * a.Ho + y) * a.Wo + xx) * cout + tg * 32) * (long)EB + ch * 16) = v;
+                }
+            }
+            if constexpr (F24) {
+                const int crl = (ncol + 15) >> 4;
+                const unsigned magl = (65536u + crl - 1) / crl;
+                for (int c = lane; c < 32 * crl; c += 64) {
+                    const int q = (int)(((unsigned)c * magl) >> 16), ch = c - q * crl;
+                    const int qpx = rt * 32 + q;
+                    const unsigned qy = div32(qpx, g.d_tw), qx = qpx - qy * a.TW;
+                    const int y = oy0 + (int)qy, xx = ox0 + (int)qx;
+                    if (qpx < x.npx && y < a.Ho && xx < a.Wo) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(stage_lo + q * PITCH_LO + ch * 16);
+                        *reinterpret_cast<u32x4*>(x.e.y_lo + (((long)n * a.Ho + y) * a.Wo + xx) * LPo + tg * 32 + ch * 16) = v;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -731,9 +850,14 @@ static const DwpTileEntry kDwpTilesF32[] = {
     {88, 24, 28, 3, 1, 24, 4, 28},        // mobilenetv3_small features.3: 0.148 vs 0.202 ms
 };
 
-static bool dwp_pick(bool f32, int k, int s, int C, int Ho, int Wo, int cout, int cin, DwpPlan* out) {
+static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int cin, DwpPlan* out) {
+    const bool f32 = fmt != FMT_BF16;                     // fp32-class arithmetic: hi + lo planes, fp32 expanded tile
+    const bool f24 = fmt == FMT_F24;
     const int CV = C / 8, sw = s == 2 ? 2 : 4;
-    const int ns = f32 ? 2 : 1, es = f32 ? 4 : 2;
+    const int ns = f32 ? 2 : 1;
+    // output staging per block: 4 waves x 32 pixels x 64 channels (f24: a bf16-shaped tile for the hi halves + a byte tile)
+    const size_t stage_bytes = 4 * 32 * (f24 ? (size_t)stage_pitch(2 * 32 * 2) + stage_pitch_lo(2 * 32) : (size_t)stage_pitch(2 * 32 * (f32 ? 4 : 2)));
+    const size_t in_px_bytes = f24 ? (size_t)cin * 2 + f24_lo_pitch(cin) : (size_t)cin * (f32 ? 4 : 2);   // staged block input per pixel (expand form)
     if (C % 8 || CV > 16 || C > 128 || cout % 8 || cout > 128 || (k != 3 && k != 5) || (s != 1 && s != 2)) return false;
     // fp32 plans without the expand conv: measured per shape on mobilenetv1 / v3 (512-image launches), the fused form wins
     // for 16..32 channels (0.146 vs 0.170 ms, 0.130 vs 0.178, 0.079 vs 0.094, 0.34 vs 0.43) and loses for 8 channels
@@ -778,14 +902,16 @@ static bool dwp_pick(bool f32, int k, int s, int C, int Ho, int Wo, int cout, in
         const double IH = (th - 1) * s + k, IW = (tw - 1) * s + k;
         // tile + taps + bias; a tile computed in the kernel has one spare vector slot per pixel, so that the
         // MFMA lanes (one pixel each) write it without bank conflicts
-        const size_t tile = dw_lds_bytes(f32, k, s, th, tw, CV) + (cin ? (size_t)(IH * IW) * (f32 ? 32 : 16) : 0);
+        // (a tile computed in the kernel is fp32 half-planes for both fp32-class formats; one staged from HBM is in the plan's format)
+        const int tfmt = cin ? (f32 ? FMT_F32 : FMT_BF16) : fmt;
+        const size_t tile = dw_lds_bytes(tfmt, k, s, th, tw, CV) + (cin ? (size_t)(IH * IW) * (f32 ? 32 : 16) : 0);
         // the output staging tiles live behind the depthwise result, inside the (by then dead) input tile
         const size_t off_stage = align_up(dwo, 16);
-        const size_t off_wp = align_up(std::max(tile, off_stage + 4 * 32 * (size_t)stage_pitch(2 * 32 * es)), 1024);
+        const size_t off_wp = align_up(std::max(tile, off_stage + stage_bytes), 1024);
         const size_t off_pb = off_wp + (size_t)NT * KS * ns * 1024;
         const size_t off_we = off_pb + (size_t)NT * 256;
         const size_t off_in = off_we + (size_t)NTe * KSe * ns * 1024;
-        const size_t lds = off_in + (cin ? align_up((size_t)(IH * IW) * cin * es, 16) + (size_t)NTe * 256 : 0);
+        const size_t lds = off_in + (cin ? align_up((size_t)(IH * IW) * in_px_bytes, 16) + (size_t)NTe * 256 : 0);
         if (lds > cap) continue;
         const double useful = (double)std::min(th, Ho) * std::min(tw, Wo);
         // staged input per useful output, padded MFMA rows, and a preference for >= 3 blocks per CU
@@ -799,9 +925,9 @@ static bool dwp_pick(bool f32, int k, int s, int C, int Ho, int Wo, int cout, in
     return found;
 }
 
-bool dwp_supported(bool f32, int k, int stride, int C, int Ho, int Wo, int cout, int cin) {
+bool dwp_supported(int fmt, int k, int stride, int C, int Ho, int Wo, int cout, int cin) {
     DwpPlan pl;
-    return dwp_pick(f32, k, stride, C, Ho, Wo, cout, cin, &pl);
+    return dwp_pick(fmt, k, stride, C, Ho, Wo, cout, cin, &pl);
 }
 
 template <typename T>
@@ -822,10 +948,13 @@ static int launch_dwp_t(int k, int stride, const DwpArgs& x, const DwGeom& g, co
     return FR_OK;
 }
 
-int launch_dwp(bool f32, int k, int stride, DwArgs a, const bf16* wp, const EpiArgs& e, const DwpExpand* ex, hipStream_t st) {
+int launch_dwp(int fmt, int k, int stride, DwArgs a, const bf16* wp, const EpiArgs& e, const DwpExpand* ex, hipStream_t st) {
     DwpPlan pl;
+    const bool f32 = fmt != FMT_BF16;
     const int cin = ex ? ex->Cin : 0;
-    if (!a.zeros || a.N <= 0 || !dwp_pick(f32, k, stride, a.C, a.Ho, a.Wo, e.cout, cin, &pl)) FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: shape not supported");
+    if (!a.zeros || a.N <= 0 || !dwp_pick(fmt, k, stride, a.C, a.Ho, a.Wo, e.cout, cin, &pl)) FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: shape not supported");
+    if (fmt == FMT_F24 && (!e.y_lo || (e.residual && !e.residual_lo) || (ex ? !ex->xin_lo : !a.x_lo)))
+        FR_FAIL(FR_ERR_ARG, "dw+1x1: f24 tensors without their lo planes");
     if ((long)a.H * a.W * a.C * 4 >= 0x7FFFFFFFL) FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: image above 2 GB");
     a.TH = pl.TH; a.TW = pl.TW; a.CBV = a.C / 8; a.cchunks = 1;
     a.tiles_y = cdiv(a.Ho, a.TH); a.tiles_x = cdiv(a.Wo, a.TW);
@@ -836,15 +965,17 @@ int launch_dwp(bool f32, int k, int stride, DwArgs a, const bf16* wp, const EpiA
     g.IH = (a.TH - 1) * stride + k; g.IW = (a.TW - 1) * stride + k;
     g.nstrips = a.TW / sw;
     g.nitems = a.TH * g.nstrips * a.CBV;
-    g.nunits = g.IH * g.IW * a.CBV * (f32 ? 2 : 1);
+    g.nunits = g.IH * g.IW * a.CBV * (fmt == FMT_F32 ? 2 : 1);
     g.PP = ex ? a.CBV + 1 : a.CBV;
+    g.PPL = (a.CBV + 1) / 2;
+    g.tile_bytes = (int)dw_tile_bytes(ex ? (f32 ? FMT_F32 : FMT_BF16) : fmt, g.IH, g.IW, g.PP);
     g.d_cbv = make_div32(a.CBV); g.d_iw = make_div32(g.IW); g.d_ns = make_div32(g.nstrips); g.d_tw = make_div32(a.TW);
     DwpArgs x{};
     x.dw = a; x.wp = wp; x.e = e; x.KS = cdiv(a.C, 16); x.NT = cdiv(e.cout, 32);
     x.npx = a.TH * a.TW; x.npx_pad = pl.npx_pad; x.pitch = pl.pitch; x.off_lo = pl.off_lo;
     x.off_wp = pl.off_wp; x.off_stage = pl.off_stage; x.off_pb = pl.off_pb;
     if (ex) {
-        x.xin = ex->xin; x.we = ex->we; x.be = ex->bias; x.se = ex->slope; x.act_e = ex->act; x.Cin = ex->Cin;
+        x.xin = ex->xin; x.xin_lo = ex->xin_lo; x.we = ex->we; x.be = ex->bias; x.se = ex->slope; x.act_e = ex->act; x.Cin = ex->Cin;
         x.KSe = cdiv(ex->Cin, 16); x.NTe = cdiv(a.C, 32); x.off_we = pl.off_we; x.off_in = pl.off_in;
         x.d_cin8 = make_div32(ex->Cin / 8);
     }
@@ -852,7 +983,8 @@ int launch_dwp(bool f32, int k, int stride, DwArgs a, const bf16* wp, const EpiA
         g.n0 = n0;
         dim3 grid((unsigned)a.tiles_x, (unsigned)a.tiles_y, (unsigned)std::min(65535, a.N - n0));
         dw_block_geom(g, (int)grid.x, (int)grid.y, (int)grid.z);
-        const int rc = f32 ? launch_dwp_t<float>(k, stride, x, g, pl, ex != nullptr, grid, st)
+        const int rc = fmt == FMT_F24 ? launch_dwp_t<f24>(k, stride, x, g, pl, ex != nullptr, grid, st)
+                     : f32 ? launch_dwp_t<float>(k, stride, x, g, pl, ex != nullptr, grid, st)
                            : launch_dwp_t<bf16>(k, stride, x, g, pl, ex != nullptr, grid, st);
         if (rc) return rc;
     }

@@ -15,7 +15,11 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
     const int cv0 = ch * 32, ncv = min(32, CV - cv0);
     const int PS = 256 / ncv;
     const int cv = threadIdx.x % ncv, ps = threadIdx.x / ncv;
-    const T* X = reinterpret_cast<const T*>(a.x) + (long)n * a.P * a.C + (cv0 + cv) * 8;
+    typedef typename act_hi<T>::type TH;
+    const TH* X = reinterpret_cast<const TH*>(a.x) + (long)n * a.P * a.C + (cv0 + cv) * 8;
+    const int LP = f24_lo_pitch(a.C);
+    const unsigned char* XL = kIsF24<T> ? a.x_lo + (long)n * a.P * LP + (cv0 + cv) * 8 : nullptr;
+    (void)XL;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (ps < PS) {
         // four loads in flight per thread; the summation order (p ascending) is unchanged
@@ -25,7 +29,8 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
             for (int q = 0; q < 4; ++q) {
                 const int p = p0 + q * PS;
                 const int pc = p < a.P ? p : ps;
-                v[q] = load8(X + (long)pc * a.C);
+                if constexpr (kIsF24<T>) v[q] = f24_load8(X + (long)pc * a.C, XL + (long)pc * LP);
+                else v[q] = load8(X + (long)pc * a.C);
                 if (a.w) w[q] = load8(a.w + (long)pc * a.C + (cv0 + cv) * 8);
             }
 #pragma unroll
@@ -56,11 +61,13 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
     }
 }
 
-int launch_reduce(bool f32, const ReduceArgs& a, hipStream_t st) {
+int launch_reduce(int fmt, const ReduceArgs& a, hipStream_t st) {
     if (a.C % 8 || a.N <= 0 || a.P <= 0) FR_FAIL(FR_ERR_ARG, "reduce: C must be a multiple of 8");
+    if (fmt == FMT_F24 && !a.x_lo) FR_FAIL(FR_ERR_ARG, "reduce: f24 input without its lo plane");
     const int nchunk = cdiv(a.C / 8, 32);
     dim3 grid((unsigned)((long)a.N * nchunk));
-    if (f32) hipLaunchKernelGGL((reduce_kernel<float>), grid, dim3(256), 0, st, a);
+    if (fmt == FMT_F24) hipLaunchKernelGGL((reduce_kernel<f24>), grid, dim3(256), 0, st, a);
+    else if (fmt == FMT_F32) hipLaunchKernelGGL((reduce_kernel<float>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((reduce_kernel<bf16>), grid, dim3(256), 0, st, a);
     FR_LAUNCH_CHECK("reduce_kernel");
     return FR_OK;
@@ -82,18 +89,46 @@ __global__ void nhwc_to_nchw_kernel(const T* x, float* y, long total, int C, int
         y[i] = (float)x[(n * HW + p) * C + c];
     }
 }
-int launch_nchw_to_nhwc(const float* x, void* y, bool y_f32, int N, int C, int H, int W, hipStream_t st) {
+// f24 forms: one thread per 8 channels of a pixel (C % 8 == 0)
+__global__ void nchw_to_nhwc_f24_kernel(const float* x, bf16* y, unsigned char* y_lo, long total8, int C, int HW) {
+    const int CV = C >> 3, LP = f24_lo_pitch(C);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+        const int cv = i % CV; const long m = i / CV;
+        const long p = m % HW, n = m / HW;
+        Vec8f v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v.v[j] = x[(n * C + cv * 8 + j) * HW + p];
+        f24_store8(y + m * C + cv * 8, y_lo + m * LP + cv * 8, v);
+    }
+}
+__global__ void nhwc_to_nchw_f24_kernel(const bf16* x, const unsigned char* x_lo, float* y, long total8, int C, int HW) {
+    const int CV = C >> 3, LP = f24_lo_pitch(C);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+        const int cv = i % CV; const long m = i / CV;
+        const long p = m % HW, n = m / HW;
+        const Vec8f v = f24_load8(x + m * C + cv * 8, x_lo + m * LP + cv * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[(n * C + cv * 8 + j) * HW + p] = v.v[j];
+    }
+}
+int launch_nchw_to_nhwc(const float* x, void* y, void* y_lo, int fmt, int N, int C, int H, int W, hipStream_t st) {
     const long total = (long)N * C * H * W;
     const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 65536);
-    if (y_f32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(grid), dim3(256), 0, st, x, (float*)y, total, C, H * W);
+    if (fmt == FMT_F24) {
+        if (C % 8 || !y_lo) FR_FAIL(FR_ERR_UNSUPPORTED, "nchw_to_nhwc (f24): C must be a multiple of 8");
+        hipLaunchKernelGGL(nchw_to_nhwc_f24_kernel, dim3(grid), dim3(256), 0, st, x, (bf16*)y, (unsigned char*)y_lo, total / 8, C, H * W);
+    } else if (fmt == FMT_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(grid), dim3(256), 0, st, x, (float*)y, total, C, H * W);
     else hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16>), dim3(grid), dim3(256), 0, st, x, (bf16*)y, total, C, H * W);
     FR_LAUNCH_CHECK("nchw_to_nhwc_kernel");
     return FR_OK;
 }
-int launch_nhwc_to_nchw(const void* x, bool x_f32, float* y, int N, int C, int H, int W, hipStream_t st) {
+int launch_nhwc_to_nchw(const void* x, const void* x_lo, int fmt, float* y, int N, int C, int H, int W, hipStream_t st) {
     const long total = (long)N * C * H * W;
     const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 65536);
-    if (x_f32) hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, y, total, C, H * W);
+    if (fmt == FMT_F24) {
+        if (C % 8 || !x_lo) FR_FAIL(FR_ERR_UNSUPPORTED, "nhwc_to_nchw (f24): C must be a multiple of 8");
+        hipLaunchKernelGGL(nhwc_to_nchw_f24_kernel, dim3(grid), dim3(256), 0, st, (const bf16*)x, (const unsigned char*)x_lo, y, total / 8, C, H * W);
+    } else if (fmt == FMT_F32) hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, y, total, C, H * W);
     else hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16>), dim3(grid), dim3(256), 0, st, (const bf16*)x, y, total, C, H * W);
     FR_LAUNCH_CHECK("nhwc_to_nchw_kernel");
     return FR_OK;

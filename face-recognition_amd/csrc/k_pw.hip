@@ -67,6 +67,25 @@ struct XFrag<float> {
     }
 };
 
+template <>
+struct XFrag<f24> {
+    bf16x8 hi, lo;
+    FR_DEV void zero() { hi = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; lo = hi; }
+    // p: 8 channels of the hi plane, pl: the same 8 channels of the lo plane
+    FR_DEV void load(const bf16* p, const unsigned char* pl, const float* se) {
+        const u32x4 h = *reinterpret_cast<const u32x4*>(p);
+        const unsigned long long l = *reinterpret_cast<const unsigned long long*>(pl);
+        if (se) {
+            Vec8f x = f24_decode(h, (unsigned)l, (unsigned)(l >> 32)), s = load8(se);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x.v[i] *= s.v[i];
+            split8(x, hi, lo);
+        } else {
+            f24_frags(h, (unsigned)l, (unsigned)(l >> 32), hi, lo);
+        }
+    }
+};
+
 template <typename TIn, typename TOut, int NTB>
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwArgs a, PwGrid pg) {
     constexpr bool SPLIT = std::is_same<TIn, float>::value;
@@ -186,11 +205,13 @@ constexpr int PJ_IMGS = 4;        // images a 128-pixel super-tile can span (nee
 // are the narrow outputs of the project convs: <= 160 channels, 64 contiguous bytes per lane).
 template <bool SE, typename T>
 __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
-    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr bool F32 = kWide<T>;                      // fp32-class arithmetic: fp32 or f24 activations
+    constexpr bool F24 = kIsF24<T>;
+    typedef typename act_hi<T>::type TH;
     constexpr int NS = F32 ? 2 : 1;
     constexpr int CK = F32 ? 2 : 4;                     // k-steps per chunk
-    constexpr int XU = F32 ? 2 : 1;                     // 16-byte units of one lane's 8 input channels
-    struct Raw { u32x4 x[CK][XU]; };
+    constexpr int XU = (F32 && !F24) ? 2 : 1;           // 16-byte units of one lane's 8 input channels (f24: the hi plane's)
+    struct Raw { u32x4 x[CK][XU]; unsigned long long xl[F24 ? CK : 1]; };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WBUF = PJ_NT * CK * NS * 1024;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -199,7 +220,8 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
     const int nt = min(a.ntg, a.NT - t0);
     const int nch = (a.KS + CK - 1) / CK;
     const long n_super = (a.M + 127) / 128;
-    const T* X = reinterpret_cast<const T*>(a.x);
+    const TH* X = reinterpret_cast<const TH*>(a.x);
+    const int LPK = f24_lo_pitch(a.K);
     constexpr int SG = 2;
     constexpr int PITCH = stage_pitch(SG * 64);
     constexpr int STAGE_BYTES = F32 ? 0 : 4 * 32 * PITCH;
@@ -213,7 +235,9 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
         const long m = st * 128 + wave * 32 + p;
         const bool m_ok = m < a.M;
         const long mc = m_ok ? m : a.M - 1;
-        const T* xrow = X + mc * (long)a.K;
+        const TH* xrow = X + mc * (long)a.K;
+        const unsigned char* xlrow = F24 ? a.x_lo + mc * (long)LPK : nullptr;
+        (void)xlrow;
         const long img0 = (st * 128) / a.HW;
         const float* srow = sc + (int)(mc / a.HW - img0) * a.K;
         if constexpr (SE) {
@@ -246,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
                 const int kc = kk < a.K ? kk : 0;                       // clamped: the k-step is skipped or its weights are zero
 #pragma unroll
                 for (int u = 0; u < XU; ++u) raw.x[j][u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(xrow + kc) + 16 * u);
+                if constexpr (F24) raw.xl[j] = *reinterpret_cast<const unsigned long long*>(xlrow + kc);
             }
         };
 
@@ -264,9 +289,13 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
                 if (j < ns) {
                     bf16x8 xf, xl;
                     const bool live = (s0 + j) * 16 + 8 * h < a.K;
-                    if constexpr (SE || F32) {
+                    if constexpr (F24 && !SE) {
+                        f24_frags(raw.x[j][0], (unsigned)raw.xl[j], (unsigned)(raw.xl[j] >> 32), xf, xl);
+                    } else if constexpr (SE || F32) {
                         Vec8f x;
-                        if constexpr (F32) {
+                        if constexpr (F24) {
+                            x = f24_decode(raw.x[j][0], (unsigned)raw.xl[j], (unsigned)(raw.xl[j] >> 32));
+                        } else if constexpr (F32) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) { x.v[i] = __uint_as_float(raw.x[j][0][i]); x.v[4 + i] = __uint_as_float(raw.x[j][XU - 1][i]); }
                         } else {
@@ -321,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
         if constexpr (F32) {
 #pragma unroll
             for (int t = 0; t < PJ_NT; ++t)
-                if (t < nt) epilogue_store<float>(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok);
+                if (t < nt) epilogue_store<T>(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok);
         } else {
             const long tile0 = m - p, left = a.M - tile0;
 #pragma unroll
@@ -341,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
 
 template <typename T>
 static int launch_pw_proj(const PwArgs& a, hipStream_t st) {
-    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr bool F32 = kWide<T>;
     const long n_super = (a.M + 127) / 128;
     PwArgs b = a;
     b.ntg = PJ_NT;
@@ -366,7 +395,11 @@ template <typename TIn, typename TOut, int NTB, int MT, int KSM = 8 / MT, int SG
 __global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) {
     // TIn = float (fp32 plans): fp32 activations are split into bf16 hi + lo on load and every product is three
     // MFMA passes against the hi/lo weight fragments, in the order pw_gemm_kernel uses (same bits either way)
-    constexpr bool SPLIT = std::is_same<TIn, float>::value;
+    constexpr bool SPLIT = kWide<TIn>;
+    constexpr bool F24 = kIsF24<TIn>;                                    // f24 goes in and out together
+    static_assert(kIsF24<TIn> == kIsF24<TOut>, "f24 plans: input and output are both f24");
+    typedef typename act_hi<TIn>::type THI;
+    typedef typename act_hi<TOut>::type THO;
     constexpr int NS = SPLIT ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -391,16 +424,20 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    const TIn* X = reinterpret_cast<const TIn*>(a.x);
-    const TOut* R = reinterpret_cast<const TOut*>(a.e.residual);
-    TOut* Y = reinterpret_cast<TOut*>(a.e.y);
+    const THI* X = reinterpret_cast<const THI*>(a.x);
+    const THO* R = reinterpret_cast<const THO*>(a.e.residual);
+    THO* Y = reinterpret_cast<THO*>(a.e.y);
     const long per_iter = 128L * MT;
     const long n_iter = (a.M + per_iter - 1) / per_iter;
     const int cout = a.e.cout;
-    constexpr bool STAGED = true;                          // bf16 and fp32 outputs both leave through a wave-private LDS tile
+    constexpr bool STAGED = true;                          // bf16, fp32 and f24 outputs all leave through a wave-private LDS tile
     constexpr bool OUT32 = std::is_same<TOut, float>::value;
-    constexpr int PITCH = stage_pitch(SG * 32 * (int)sizeof(TOut));
+    constexpr int PITCH = stage_pitch(SG * 32 * kHiBytes<TOut>);
+    constexpr int PITCH_LO = stage_pitch_lo(SG * 32);      // f24: second tile for the lo bytes
     unsigned char* stage = smem + (size_t)NTB * KS * NS * 1024 + (size_t)NTB * 256 + (size_t)wave * 32 * PITCH;
+    unsigned char* stage_lo = smem + (size_t)NTB * KS * NS * 1024 + (size_t)NTB * 256 + (size_t)4 * 32 * PITCH + (size_t)wave * 32 * PITCH_LO;
+    const int LPK = f24_lo_pitch(a.K), LPC = f24_lo_pitch(cout);
+    (void)stage_lo; (void)LPK; (void)LPC;
 
     for (long it = bx; it < n_iter; it += pg.gx) {
         const long mbase = it * per_iter + (long)wave * 32 * MT + p;
@@ -409,13 +446,15 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) 
         for (int mt = 0; mt < MT; ++mt) {
             const long m = mbase + mt * 32;
             const long mc = m < a.M ? m : a.M - 1;
-            const TIn* xrow = X + mc * (long)a.K;
+            const THI* xrow = X + mc * (long)a.K;
             const float* serow = a.se ? a.se + (mc / a.HW) * (long)a.K : nullptr;
 #pragma unroll
             for (int s = 0; s < KSM; ++s) {
                 const int kk = s * 16 + 8 * h;
-                if (s < KS && kk < a.K) xf[mt][s].load(xrow + kk, serow ? serow + kk : nullptr);
-                else xf[mt][s].zero();
+                if (s < KS && kk < a.K) {
+                    if constexpr (F24) xf[mt][s].load(xrow + kk, a.x_lo + mc * (long)LPK + kk, serow ? serow + kk : nullptr);
+                    else xf[mt][s].load(xrow + kk, serow ? serow + kk : nullptr);
+                } else xf[mt][s].zero();
             }
         }
 #pragma unroll
@@ -452,11 +491,19 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) 
                                 act8(v, a.e.act, bl + NTB * 32 + cl);
                                 const long off = m * (long)cout + c;
                                 if (R) {
-                                    const Vec8f r = load8(R + off);
+                                    Vec8f r;
+                                    if constexpr (F24) r = f24_load8(R + off, a.e.residual_lo + m * (long)LPC + c);
+                                    else r = load8(R + off);
 #pragma unroll
                                     for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
                                 }
-                                if constexpr (OUT32) stage_put_f32(stage, PITCH, p, cl - (t / SG) * SG * 32, v);
+                                if constexpr (F24) {
+                                    const int col = cl - (t / SG) * SG * 32;
+                                    u32x4 hh; unsigned l0, l1;
+                                    f24_encode(v, hh, l0, l1);
+                                    *reinterpret_cast<u32x4*>(stage + p * PITCH + col * 2) = hh;
+                                    *reinterpret_cast<unsigned long long*>(stage_lo + p * PITCH_LO + col) = (unsigned long long)l0 | ((unsigned long long)l1 << 32);
+                                } else if constexpr (OUT32) stage_put_f32(stage, PITCH, p, cl - (t / SG) * SG * 32, v);
                                 else stage_put(stage, PITCH, p, cl - (t / SG) * SG * 32, v);
                             }
                         }
@@ -473,6 +520,9 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) 
                                 else
                                     stage_flush(stage, PITCH, lane, reinterpret_cast<bf16*>(Y) + tile0 * cout + (t0 + tg) * 32, cout,
                                                 min(SG * 32, cout - (t0 + tg) * 32), left < 32 ? (int)left : 32);
+                                if constexpr (F24)
+                                    stage_flush_lo(stage_lo, PITCH_LO, lane, a.e.y_lo + tile0 * LPC + (t0 + tg) * 32, LPC,
+                                                   min(SG * 32, cout - (t0 + tg) * 32), left < 32 ? (int)left : 32);
                             }
                         }
                     }
@@ -606,7 +656,7 @@ void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks) {
 
 template <typename TIn, typename TOut, int NTB, int SG>
 static int launch_pw_stream_sg(const PwArgs& a, hipStream_t st) {
-    constexpr int NS = std::is_same<TIn, float>::value ? 2 : 1;
+    constexpr int NS = kWide<TIn> ? 2 : 1;
     // pixel tiles per wave: 8 operand fragments per lane in flight for bf16, 4 (hi + lo each) for fp32 up to K = 64
     int mt = NS == 2 ? (a.KS <= 2 ? 2 : 1) : (a.KS <= 2 ? 4 : (a.KS <= 4 ? 2 : (a.KS <= 8 ? 1 : 0)));
     static const int mt_env = getenv("FR_PW_MT") ? atoi(getenv("FR_PW_MT")) : 0;           // tuning: cap on pixel tiles per wave
@@ -622,7 +672,8 @@ static int launch_pw_stream_sg(const PwArgs& a, hipStream_t st) {
     const PwGrid pg{(int)std::min<long>(n_iter, want), ng};
     dim3 grid(pw_grid_blocks(pg.gx, pg.ng));
     size_t lds = (size_t)NTB * a.KS * NS * 1024 + (size_t)NTB * 256;
-    lds += 4 * 32 * (size_t)stage_pitch(SG * 32 * (int)sizeof(TOut));
+    lds += 4 * 32 * (size_t)stage_pitch(SG * 32 * kHiBytes<TOut>);
+    if (kIsF24<TOut>) lds += 4 * 32 * (size_t)stage_pitch_lo(SG * 32);
 #define FR_PW_GO(MT_, KSM_) do { FR_BIG_LDS((pw_stream_kernel<TIn, TOut, NTB, MT_, KSM_, SG>), lds); \
         hipLaunchKernelGGL((pw_stream_kernel<TIn, TOut, NTB, MT_, KSM_, SG>), grid, dim3(256), lds, st, a, pg); } while (0)
     if constexpr (NS == 2) {
@@ -659,7 +710,7 @@ static int launch_pw_t(const PwArgs& a, int ntb, hipStream_t st) {
                 default: break;
             }
         }
-    } else if constexpr (std::is_same<TOut, float>::value) {
+    } else if constexpr (kWide<TOut>) {
         if (a.KS <= 8 && a.chunk_ks >= a.KS) {
             switch (ntb) {
                 case 1: return launch_pw_stream<TIn, TOut, 1>(a, st);
@@ -669,6 +720,9 @@ static int launch_pw_t(const PwArgs& a, int ntb, hipStream_t st) {
             }
         }
     }
+    if constexpr (kIsF24<TIn> || kIsF24<TOut>) {
+        FR_FAIL(FR_ERR_UNSUPPORTED, "pw: f24 plans have no k-chunked 1x1 kernel for this shape (K <= 128, or K > 128 with H*W >= 43 behind squeeze-excite)");
+    } else {
     constexpr int NS = std::is_same<TIn, float>::value ? 2 : 1;
     const long n_super = (a.M + 127) / 128;
     const PwGrid pg{(int)std::min<long>(n_super, 2048), cdiv(a.NT, ntb)};
@@ -685,30 +739,41 @@ static int launch_pw_t(const PwArgs& a, int ntb, hipStream_t st) {
     }
     FR_LAUNCH_CHECK("pw_gemm_kernel");
     return FR_OK;
+    }
 }
 
 // Which kernel launch_pw picks for a layer shape (diagnostics: fr_plan_layer_kernel, bench.py).
-const char* pw_kernel_name(bool in_f32, bool out_f32, int K, int cout, bool se, int HW) {
+const char* pw_kernel_name(int in_fmt, int out_fmt, int K, int cout, bool se, int HW) {
+    const bool in_w = in_fmt != FMT_BF16, out_w = out_fmt != FMT_BF16;
     const int KS = cdiv(K, 16), NT = cdiv(cout, 32);
     int ntb, ck;
-    pw_pick_tiling(in_f32, NT, KS, &ntb, &ck);
-    if (in_f32 && out_f32 && KS > 8 && (!se || HW >= 43) && !(getenv("FR_PW_F32_PROJ") && atoi(getenv("FR_PW_F32_PROJ")) == 0)) return "pw_proj_kernel";
-    if (in_f32) return (out_f32 && KS <= 8 && ck >= KS) ? "pw_stream_kernel" : "pw_gemm_kernel";
-    if (!out_f32 && KS > 16 && (!se || HW >= 43)) return "pw_proj_kernel";
+    pw_pick_tiling(in_w, NT, KS, &ntb, &ck);
+    if (in_w && out_w && KS > 8 && (!se || HW >= 43) && !(getenv("FR_PW_F32_PROJ") && atoi(getenv("FR_PW_F32_PROJ")) == 0)) return "pw_proj_kernel";
+    if (in_w) return (out_w && KS <= 8 && ck >= KS) ? "pw_stream_kernel" : "pw_gemm_kernel";
+    if (!out_w && KS > 16 && (!se || HW >= 43)) return "pw_proj_kernel";
     if (KS <= 16 && ck >= KS && (KS <= 8 || ntb <= 2)) return "pw_stream_kernel";
     return "pw_gemm_kernel";
 }
 
-int launch_pw(bool in_f32, bool out_f32, const PwArgs& a, hipStream_t st) {
+int launch_pw(int in_fmt, int out_fmt, const PwArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.K <= 0 || a.K % 8 || a.e.cout % 8 || a.KS != cdiv(a.K, 16) || a.NT != cdiv(a.e.cout, 32))
         FR_FAIL(FR_ERR_ARG, "pw: inconsistent shapes (K and Cout must be multiples of 8)");
+    const bool in_w = in_fmt != FMT_BF16;
     int ntb, ck;
-    pw_pick_tiling(in_f32, a.NT, a.KS, &ntb, &ck);
+    pw_pick_tiling(in_w, a.NT, a.KS, &ntb, &ck);
     if (ck != a.chunk_ks) FR_FAIL(FR_ERR_ARG, "pw: chunk_ks does not match pw_pick_tiling");
     static const bool proj32 = !(getenv("FR_PW_F32_PROJ") && atoi(getenv("FR_PW_F32_PROJ")) == 0);
-    if (in_f32 && out_f32 && proj32 && a.KS > 8 && (!a.se || (a.HW >= 43 && a.M % a.HW == 0))) return launch_pw_proj<float>(a, st);
+    const bool proj_ok = !a.se || (a.HW >= 43 && a.M % a.HW == 0);
+    if (in_fmt == FMT_F24 || out_fmt == FMT_F24) {
+        if (in_fmt != out_fmt) FR_FAIL(FR_ERR_UNSUPPORTED, "pw: f24 input and output go together");
+        if (!a.x_lo || !a.e.y_lo || (a.e.residual && !a.e.residual_lo)) FR_FAIL(FR_ERR_ARG, "pw: f24 tensors without their lo planes");
+        if (a.KS > 8 && proj_ok) return launch_pw_proj<f24>(a, st);
+        return launch_pw_t<f24, f24>(a, ntb, st);
+    }
+    const bool in_f32 = in_fmt == FMT_F32, out_f32 = out_fmt == FMT_F32;
+    if (in_f32 && out_f32 && proj32 && a.KS > 8 && proj_ok) return launch_pw_proj<float>(a, st);
     if (in_f32 && out_f32) return launch_pw_t<float, float>(a, ntb, st);
-    if (!in_f32 && !out_f32 && a.KS > 16 && (!a.se || (a.HW >= 43 && a.M % a.HW == 0))) return launch_pw_proj<bf16>(a, st);
+    if (!in_f32 && !out_f32 && a.KS > 16 && proj_ok) return launch_pw_proj<bf16>(a, st);
     if (!in_f32 && !out_f32) return launch_pw_t<bf16, bf16>(a, ntb, st);
     if (!in_f32 && out_f32) return launch_pw_t<bf16, float>(a, ntb, st);
     FR_FAIL(FR_ERR_UNSUPPORTED, "pw: fp32 input with bf16 output is not instantiated");

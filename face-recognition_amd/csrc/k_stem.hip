@@ -160,6 +160,32 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+            } else if constexpr (kIsF24<TOut>) {
+                // f24: the hi halves take the bf16 route; the lo bytes (32 per pixel and n-tile) a second tile
+                constexpr int PITCH = 64 + 16, PITCH_LO = stage_pitch_lo(32);
+                unsigned char* stage = smem + a.stage_off + wave * 32 * (PITCH + PITCH_LO);
+                unsigned char* stage_lo = stage + 32 * PITCH;
+                epilogue_stage_f24(acc, a.e, m, 32 * t + 16 * h, true, stage, PITCH, stage_lo, PITCH_LO, p, 16 * h);
+                const int ncol = min(32, a.e.cout - 32 * t), cr = ncol >> 3, crl = (ncol + 15) >> 4;
+                const int LP = f24_lo_pitch(a.e.cout);
+                __builtin_amdgcn_wave_barrier();
+                for (int c = lane; c < 32 * cr; c += 64) {
+                    const int q = c / cr, ch = c - q * cr;
+                    const int y = oy0 + 4 * sy + (q >> 3), xx = ox0 + 8 * sx + (q & 7);
+                    if (y < a.Ho && xx < a.Wo) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + q * PITCH + ch * 16);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(a.e.y) + (((long)n * a.Ho + y) * a.Wo + xx) * a.e.cout + 32 * t + ch * 8) = v;
+                    }
+                }
+                for (int c = lane; c < 32 * crl; c += 64) {
+                    const int q = c / crl, ch = c - q * crl;
+                    const int y = oy0 + 4 * sy + (q >> 3), xx = ox0 + 8 * sx + (q & 7);
+                    if (y < a.Ho && xx < a.Wo) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(stage_lo + q * PITCH_LO + ch * 16);
+                        *reinterpret_cast<u32x4*>(a.e.y_lo + (((long)n * a.Ho + y) * a.Wo + xx) * LP + 32 * t + ch * 16) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             } else {
                 epilogue_store<TOut>(acc, a.e, m, 32 * t + 16 * h, ok);
             }
@@ -167,18 +193,21 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
     }
 }
 
-int launch_stem(bool out_f32, const StemArgs& a, hipStream_t st) {
+int launch_stem(int out_fmt, const StemArgs& a, hipStream_t st) {
     if (a.e.cout % 8 || a.NT != cdiv(a.e.cout, 32) || (a.stride != 1 && a.stride != 2))
         FR_FAIL(FR_ERR_ARG, "stem: inconsistent shapes");
     if (!a.zeros) FR_FAIL(FR_ERR_ARG, "stem: no zero page");
+    if (out_fmt == FMT_F24 && !a.e.y_lo) FR_FAIL(FR_ERR_ARG, "stem: f24 output without its lo plane");
     StemArgs b = a;
     b.TW = std::min(112, cdiv(a.Wo, 8) * 8);
     const int IH = 7 * a.stride + 3, IW = (b.TW - 1) * a.stride + 3;
     size_t lds = align_up((size_t)3 * IH * IW * sizeof(float), 16);
     b.stage_off = (int)lds;
-    if (!out_f32) lds += 4 * 32 * (64 + 16);
+    if (out_fmt == FMT_BF16) lds += 4 * 32 * (64 + 16);
+    if (out_fmt == FMT_F24) lds += 4 * 32 * (64 + 16 + stage_pitch_lo(32));
     const long blocks = (long)a.N * cdiv(a.Ho, 8) * cdiv(a.Wo, b.TW);
     if (blocks > 0x7FFFFFFFL) FR_FAIL(FR_ERR_ARG, "stem: grid too large");
+    const dim3 grid((unsigned)blocks);
     if (a.x8) {
         // rows are staged as the word-aligned superset of their bytes: the base must be word aligned and an
         // image must be a whole number of words, so that the superset never leaves the caller's buffer
@@ -187,10 +216,12 @@ int launch_stem(bool out_f32, const StemArgs& a, hipStream_t st) {
         b.raw_pitch = (3 * IW + 3 + 3) & ~3;
         b.lut_off = (int)align_up((size_t)IH * b.raw_pitch, 16);
         lds = (size_t)b.raw_off + b.lut_off + 1024;
-        if (out_f32) hipLaunchKernelGGL((stem_kernel<float, true, true>), dim3((unsigned)blocks), dim3(256), lds, st, b);
-        else hipLaunchKernelGGL((stem_kernel<bf16, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, b);
-    } else if (out_f32) hipLaunchKernelGGL((stem_kernel<float, true, false>), dim3((unsigned)blocks), dim3(256), lds, st, b);
-    else hipLaunchKernelGGL((stem_kernel<bf16, false, false>), dim3((unsigned)blocks), dim3(256), lds, st, b);
+        if (out_fmt == FMT_F24) hipLaunchKernelGGL((stem_kernel<f24, true, true>), grid, dim3(256), lds, st, b);
+        else if (out_fmt == FMT_F32) hipLaunchKernelGGL((stem_kernel<float, true, true>), grid, dim3(256), lds, st, b);
+        else hipLaunchKernelGGL((stem_kernel<bf16, false, true>), grid, dim3(256), lds, st, b);
+    } else if (out_fmt == FMT_F24) hipLaunchKernelGGL((stem_kernel<f24, true, false>), grid, dim3(256), lds, st, b);
+    else if (out_fmt == FMT_F32) hipLaunchKernelGGL((stem_kernel<float, true, false>), grid, dim3(256), lds, st, b);
+    else hipLaunchKernelGGL((stem_kernel<bf16, false, false>), grid, dim3(256), lds, st, b);
     FR_LAUNCH_CHECK("stem_kernel");
     return FR_OK;
 }

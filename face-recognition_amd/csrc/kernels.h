@@ -2,9 +2,14 @@
 #pragma once
 #include "common.h"
 
+// Activation storage formats of a plan's NHWC buffers (the `fmt` / `in_fmt` / `out_fmt` arguments below).
+// FMT_F24: common.h, struct f24 -- hi plane where the bf16 tensor would be, lo plane given separately (`*_lo`).
+enum { FMT_BF16 = 0, FMT_F32 = 1, FMT_F24 = 2 };
+
 // ---- pointwise (1x1) conv / linear as MFMA GEMM:  Y[m][co] = act(sum_k X[m][k] W[co][k] + b) (+R)
 struct PwArgs {
-    const void* x;        // [M, K] activations (bf16 or fp32), row stride K
+    const void* x;        // [M, K] activations (bf16 or fp32; f24: the hi plane), row stride K
+    const unsigned char* x_lo;   // f24: lo plane [M][f24_lo_pitch(K)]
     const bf16* w;        // packed fragments [NT][KS][NS][64][8]  (NS = 2 (hi,lo) for fp32 input)
     const float* se;      // [M/HW, K] per-image channel scale applied to X on load, or NULL
     EpiArgs e;
@@ -18,16 +23,19 @@ struct PwArgs {
     int x_tiles;
     float x_scale;
 };
-int launch_pw(bool in_f32, bool out_f32, const PwArgs& a, hipStream_t st);
-const char* pw_kernel_name(bool in_f32, bool out_f32, int K, int cout, bool se, int HW);
-// Small-M form (M = batch): SE fc layers, Linear(+BN1d).  fp32 output, no SE scale, no residual.
+// in_fmt / out_fmt: FMT_*; f24 goes in and out together (FMT_F24, FMT_F24)
+int launch_pw(int in_fmt, int out_fmt, const PwArgs& a, hipStream_t st);
+const char* pw_kernel_name(int in_fmt, int out_fmt, int K, int cout, bool se, int HW);
+// Small-M form (M = batch): SE fc layers, Linear(+BN1d).  fp32 output, no SE scale, no residual.  in_f32: fp32 rows (never f24)
 int launch_fc(bool in_f32, const PwArgs& a, hipStream_t st);
-// LDS bytes per (n-tile, k-step) = 1024 * NS; used by the planner to pick chunk_ks.
-void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks);
+// LDS bytes per (n-tile, k-step) = 1024 * NS; used by the planner to pick chunk_ks.  wide: fp32-class input (FMT_F32 / FMT_F24)
+void pw_pick_tiling(bool wide, int NT, int KS, int* ntb, int* chunk_ks);
 
 // ---- depthwise KxK conv, NHWC, LDS-staged
 struct DwArgs {
     const void* x;        // [N,H,W,C]
+    const unsigned char* x_lo;   // f24: lo planes of x and y
+    unsigned char* y_lo;
     const float* w;       // [K*K][C] folded
     const float* bias;    // [C]
     const float* slope;   // [C] or NULL
@@ -43,16 +51,17 @@ struct DwArgs {
 // Optionally the expand 1x1 conv in front of the depthwise conv is computed in the same kernel too.
 struct DwpExpand {
     const void* xin;      // block input [N,H,W,Cin] (H,W = the depthwise input size), bf16 or fp32 as the plan stores it
+    const unsigned char* xin_lo;   // f24: its lo plane
     const bf16* we;       // expand weights packed [NT][KS][NS][64][8]
     const float* bias;    // padded to a multiple of 32
     const float* slope;   // PReLU slopes or NULL
     int act, Cin;
 };
-bool dwp_supported(bool f32, int k, int stride, int C, int Ho, int Wo, int cout, int cin /* 0: no expand */);
-int launch_dwp(bool f32, int k, int stride, DwArgs a, const bf16* w_pw_packed, const EpiArgs& pw_epilogue, const DwpExpand* expand, hipStream_t st);
+bool dwp_supported(int fmt, int k, int stride, int C, int Ho, int Wo, int cout, int cin /* 0: no expand */);
+int launch_dwp(int fmt, int k, int stride, DwArgs a, const bf16* w_pw_packed, const EpiArgs& pw_epilogue, const DwpExpand* expand, hipStream_t st);
 // Spatial tiles per image launch_dw will use for this layer shape (sizes DwArgs::pool).
-int dw_tiles_per_image(bool f32, int k, int stride, int C, int Ho, int Wo);
-int launch_dw(bool f32, int k, int stride, DwArgs a, hipStream_t st);
+int dw_tiles_per_image(int fmt, int k, int stride, int C, int Ho, int Wo);
+int launch_dw(int fmt, int k, int stride, DwArgs a, hipStream_t st);
 
 // ---- 3x3 stem conv, Cin = 3, fp32 NCHW in -> NHWC out, MFMA with K = 27 (padded to 32)
 struct StemArgs {
@@ -68,7 +77,7 @@ struct StemArgs {
     const float* lut;
     int raw_off, raw_pitch, lut_off;   // set by the launcher
 };
-int launch_stem(bool out_f32, const StemArgs& a, hipStream_t st);
+int launch_stem(int out_fmt, const StemArgs& a, hipStream_t st);
 
 // ---- dense KxK conv (K = 3) / large-K linear (K = 1) as MFMA implicit GEMM
 struct ConvArgs {
@@ -88,14 +97,15 @@ int conv_halo_rows(int ksize, int stride, int pad, int W, int bk);   // > 0: sha
 // ---- weighted spatial reduction: out[n][c] = sum_p x[n][p][c] * w[p][c] (+ b[c]); w NULL -> 1/P
 struct ReduceArgs {
     const void* x;        // [N,P,C]
+    const unsigned char* x_lo;   // f24: lo plane
     const float* w;       // [P][C] or NULL (mean)
     const float* bias;    // [C] or NULL
     float* out;           // [N,C] fp32
     int N, P, C;
     float scale;          // w == NULL: multiply the sum by this instead of 1/P when non-zero
 };
-int launch_reduce(bool f32, const ReduceArgs& a, hipStream_t st);
+int launch_reduce(int fmt, const ReduceArgs& a, hipStream_t st);
 
 // ---- layout conversion (plan input for non-stem first layers, taps, final non-linear outputs)
-int launch_nchw_to_nhwc(const float* x, void* y, bool y_f32, int N, int C, int H, int W, hipStream_t st);
-int launch_nhwc_to_nchw(const void* x, bool x_f32, float* y, int N, int C, int H, int W, hipStream_t st);
+int launch_nchw_to_nhwc(const float* x, void* y, void* y_lo, int fmt, int N, int C, int H, int W, hipStream_t st);
+int launch_nhwc_to_nchw(const void* x, const void* x_lo, int fmt, float* y, int N, int C, int H, int W, hipStream_t st);

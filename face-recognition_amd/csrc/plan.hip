@@ -38,8 +38,9 @@ struct Layer {
     int cin = 0, cout = 0, k = 1, stride = 1, pad = 0, act = 0;
     int inC = 0, inH = 0, inW = 0;        // input dims
     int C = 0, H = 0, W = 0;              // output dims
-    bool out_f32 = false;                 // element type of the output buffer
+    bool out_f32 = false;                 // fp32-class values in the output buffer (fp32 or f24): split GEMM operands downstream
     bool in_f32 = false;
+    int out_fmt = FMT_BF16, in_fmt = FMT_BF16;   // storage format of the output / input buffer (FMT_*; f24: hi + lo planes)
     int slot = -1;                        // output slot
     int slot_pool = -1, slot_hidden = -1; // SE extras (fp32 [N,C], [N,S]); slot = scale [N,C]
     int slot_partial = -1, pool_tiles = 0; // depthwise feeding an SE block: per-tile channel sums [N,pool_tiles,C] fp32
@@ -78,8 +79,8 @@ struct fr_plan {
     static constexpr int MAX_AUX = 3;
     hipStream_t aux[MAX_AUX] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_AUX] = {nullptr, nullptr, nullptr};
-    bool act_f32() const { return prec == FR_PREC_F32; }
-    size_t act_bytes() const { return prec == FR_PREC_F32 ? 4 : 2; }
+    bool act_f32() const { return prec != FR_PREC_BF16; }            // fp32-class arithmetic (FR_PREC_F32 and FR_PREC_F24)
+    int act_fmt() const { return prec == FR_PREC_F32 ? FMT_F32 : prec == FR_PREC_F24 ? FMT_F24 : FMT_BF16; }
     ~fr_plan() {
         for (int i = 0; i < MAX_AUX; ++i) {
             if (aux[i]) (void)hipStreamDestroy(aux[i]);
@@ -195,8 +196,9 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
     L.src = d.src; L.residual = d.residual; L.act = d.act;
     if (d.src >= idx || d.residual >= idx || d.src < -1 || d.residual < -1)
         FR_FAIL(FR_ERR_ARG, std::string(where) + "src/residual must refer to earlier layers");
-    if (d.src < 0) { L.inC = pl->in_c; L.inH = pl->in_h; L.inW = pl->in_w; L.in_f32 = af32; }
-    else { const Layer& s = pl->layers[d.src]; L.inC = s.C; L.inH = s.H; L.inW = s.W; L.in_f32 = s.out_f32; }
+    const int afmt = pl->act_fmt();
+    if (d.src < 0) { L.inC = pl->in_c; L.inH = pl->in_h; L.inW = pl->in_w; L.in_f32 = af32; L.in_fmt = afmt; }
+    else { const Layer& s = pl->layers[d.src]; L.inC = s.C; L.inH = s.H; L.inW = s.W; L.in_f32 = s.out_f32; L.in_fmt = s.out_fmt; }
     if (d.act == FR_ACT_PRELU && !d.prelu) FR_FAIL(FR_ERR_ARG, std::string(where) + "PReLU without slopes");
     if (!d.weight) FR_FAIL(FR_ERR_ARG, std::string(where) + "missing weight");
 
@@ -214,7 +216,7 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
         std::vector<double> slope_d;
         if (d.act == FR_ACT_PRELU) slope_d.assign(d.prelu, d.prelu + d.cout);
         const int cpad = cdiv(d.cout, 32) * 32;
-        L.out_f32 = af32;
+        L.out_f32 = af32; L.out_fmt = afmt;
 
         if (d.groups == 1 && d.kernel == 1) {
             if (d.stride != 1 || d.pad != 0) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "1x1 conv must be stride 1, pad 0");
@@ -246,7 +248,7 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
             int rc = upload(pl, wt, &L.w_f32); if (rc) return rc;
             if (d.pad == 0 && d.kernel == L.inH && d.kernel == L.inW) {
                 if (d.act != FR_ACT_NONE) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "global depthwise conv with activation");
-                L.kind = K_GDW; L.out_f32 = true;
+                L.kind = K_GDW; L.out_f32 = true; L.out_fmt = FMT_F32;
             } else {
                 if ((d.kernel != 3 && d.kernel != 5) || (d.stride != 1 && d.stride != 2) || d.pad != (d.kernel - 1) / 2)
                     FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "depthwise conv: k in {3,5}, stride in {1,2}, same padding");
@@ -256,6 +258,7 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
             if (d.pad != 1 || (d.stride != 1 && d.stride != 2) || d.cin % 32)
                 FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "dense 3x3 conv needs pad 1, stride 1|2, cin % 32 == 0");
             L.kind = K_CONV3;
+            if (afmt == FMT_F24) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "dense 3x3 convs have no f24 kernel (FR_PREC_F24 is the depthwise-separable families' mode; use FR_PREC_F32 or FR_PREC_BF16)");
             std::vector<uint16_t> packed;
             const int cin = d.cin;
             const int bk64_min = getenv("FR_CONV_BK64_MIN") ? atoi(getenv("FR_CONV_BK64_MIN")) : 64;   // tuning: smallest cin that uses 64-channel K slices
@@ -275,7 +278,7 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
         if (d.act == FR_ACT_PRELU) { rc = upload(pl, padded(slope_d, cpad), &L.slope); if (rc) return rc; }
         if (L.residual >= 0) {
             const Layer& r = pl->layers[L.residual];
-            if (r.C != L.C || r.H != L.H || r.W != L.W || r.out_f32 != L.out_f32 || r.kind == K_SE)
+            if (r.C != L.C || r.H != L.H || r.W != L.W || r.out_fmt != L.out_fmt || r.kind == K_SE)
                 FR_FAIL(FR_ERR_ARG, std::string(where) + "residual shape mismatch");
             if (L.kind != K_PW && L.kind != K_CONV3) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "residual only on 1x1 / 3x3 dense convs");
         }
@@ -286,7 +289,7 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
         if (d.cin != L.inC || d.cin % 8 || d.cout % 8) FR_FAIL(FR_ERR_ARG, std::string(where) + "SE channel mismatch");
         if (pl->layers[d.src].kind == K_SE) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "SE of SE");
         L.kind = K_SE; L.cin = d.cin; L.cout = d.cout;
-        L.C = L.inC; L.H = L.inH; L.W = L.inW; L.out_f32 = L.in_f32;
+        L.C = L.inC; L.H = L.inH; L.W = L.inW; L.out_f32 = L.in_f32; L.out_fmt = L.in_fmt;
         const int C = d.cin, S = d.cout;
         std::vector<double> W1(d.weight, d.weight + (size_t)S * C), W2(d.weight2, d.weight2 + (size_t)C * S);
         std::vector<uint16_t> p1, p2;
@@ -304,11 +307,12 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
         if (d.src < 0) FR_FAIL(FR_ERR_ARG, std::string(where) + "Linear needs a source layer");
         const Layer& s = pl->layers[d.src];
         if (s.kind == K_SE) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "Linear after SE");
+        if (s.out_fmt == FMT_F24) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "Linear on an f24 activation (only behind the global depthwise conv in f24 plans)");
         const int HW = s.H * s.W, K = s.C * HW;
         if (d.cin != K) FR_FAIL(FR_ERR_ARG, std::string(where) + "in_features does not match the flattened source");
         if (K % 8 || d.cout % 8) FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "Linear features must be multiples of 8");
         L.kind = K_LINEAR; L.cin = K; L.cout = d.cout; L.K = K;
-        L.C = d.cout; L.H = 1; L.W = 1; L.out_f32 = true;
+        L.C = d.cout; L.H = 1; L.W = 1; L.out_f32 = true; L.out_fmt = FMT_F32;
         std::vector<double> scale, shift;
         fold_bn(d, d.cout, scale, shift);
         // NCHW flatten index c*HW + p  ->  NHWC index p*C + c   (models/sphereface.py:126-127)
@@ -337,8 +341,12 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
     return FR_OK;
 }
 
+size_t act_bytes_per_image(int fmt, int C, int H, int W) {
+    if (fmt == FMT_F24) return (size_t)H * W * ((size_t)C * 2 + f24_lo_pitch(C));     // hi plane + lo plane (of the whole batch, back to back)
+    return (size_t)C * H * W * (fmt == FMT_F32 ? 4 : 2);
+}
 size_t layer_out_bytes(const Layer& L) {           // per image
-    return (size_t)L.C * L.H * L.W * (L.out_f32 ? 4 : 2);
+    return act_bytes_per_image(L.out_fmt, L.C, L.H, L.W);
 }
 
 }  // namespace
@@ -349,7 +357,7 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         FR_FAIL(FR_ERR_ARG, "fr_plan_create: bad arguments");
     const bool no_fuse = (precision & FR_PLAN_NO_FUSE) != 0;
     precision &= ~FR_PLAN_NO_FUSE;
-    if (precision != FR_PREC_BF16 && precision != FR_PREC_F32) FR_FAIL(FR_ERR_ARG, "fr_plan_create: bad precision");
+    if (precision != FR_PREC_BF16 && precision != FR_PREC_F32 && precision != FR_PREC_F24) FR_FAIL(FR_ERR_ARG, "fr_plan_create: bad precision");
     std::unique_ptr<fr_plan> pl(new fr_plan);
     pl->prec = precision; pl->in_c = in_c; pl->in_h = in_h; pl->in_w = in_w;
     FR_HIP_CHECK(hipGetDevice(&pl->device));
@@ -399,8 +407,8 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
     for (int i = 0; !no_fuse && i + 1 < n; ++i) {
         Layer& D = pl->layers[i];
         Layer& P = pl->layers[i + 1];
-        const bool af = pl->act_f32();
-        if (!(D.kind == K_DW && D.in_f32 == af && P.kind == K_PW && P.src == i && last_use[i] == i + 1 && P.out_f32 == af)) continue;
+        const int af = pl->act_fmt();
+        if (!(D.kind == K_DW && D.in_fmt == af && P.kind == K_PW && P.src == i && last_use[i] == i + 1 && P.out_fmt == af)) continue;
         // the expand 1x1 conv in front of the depthwise conv as well (expand -> depthwise -> project in one
         // launch, the 4x wider expanded activation never leaves LDS); FR_FUSE3=0 keeps the expand conv separate
         const bool fuse3 = !(getenv("FR_FUSE3") && atoi(getenv("FR_FUSE3")) == 0);
@@ -408,7 +416,7 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         if (fuse3 && D.src >= 0 && D.src == i - 1) {
             const Layer& E = pl->layers[i - 1];
             const bool se_in = E.src >= 0 && pl->layers[E.src].kind == K_SE;
-            with_expand = E.kind == K_PW && E.in_f32 == af && E.out_f32 == af && E.residual < 0 && !se_in && last_use[i - 1] == i &&
+            with_expand = E.kind == K_PW && E.in_fmt == af && E.out_fmt == af && E.residual < 0 && !se_in && last_use[i - 1] == i &&
                           E.fuse_src < 0 && dwp_supported(af, D.k, D.stride, D.C, D.H, D.W, P.cout, E.K);
         }
         if (!with_expand && !dwp_supported(af, D.k, D.stride, D.C, D.H, D.W, P.cout, 0)) continue;
@@ -426,7 +434,7 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
     }
     std::vector<size_t>& sizes = pl->slot_bytes;
     std::vector<char> busy;
-    if (need_input_copy) pl->input_slot = alloc_slot(sizes, busy, (size_t)in_c * in_h * in_w * pl->act_bytes());
+    if (need_input_copy) pl->input_slot = alloc_slot(sizes, busy, act_bytes_per_image(pl->act_fmt(), in_c, in_h, in_w));
     int launches = need_input_copy ? 1 : 0;
     for (int i = 0; i < n; ++i) {
         Layer& L = pl->layers[i];
@@ -444,7 +452,7 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
             // SE block never re-reads the activation (freed again once the SE layer has run)
             static const bool se_fuse = !(getenv("FR_SE_FUSE") && atoi(getenv("FR_SE_FUSE")) == 0);
             if (se_fuse && L.kind == K_DW && L.fuse_src < 0 && i + 1 < n && pl->layers[i + 1].kind == K_SE && pl->layers[i + 1].src == i) {
-                const int T = dw_tiles_per_image(L.in_f32, L.k, L.stride, L.C, L.H, L.W);
+                const int T = dw_tiles_per_image(L.in_fmt, L.k, L.stride, L.C, L.H, L.W);
                 if (T > 0) { L.pool_tiles = T; L.slot_partial = alloc_slot(sizes, busy, (size_t)T * L.C * 4); if (T <= 8) launches -= 1; }   // <= 8 tiles: fc1 folds them, no reduce launch
             }
         }
@@ -519,12 +527,19 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
         unsigned char* p = reinterpret_cast<unsigned char*>(align_up((size_t)workspace, 256));
         for (size_t i = 0; i < base.size(); ++i) { base[i] = p; p += align_up(plan->slot_bytes[i] * (size_t)N, 256); }
     }
-    const bool af32 = plan->act_f32();
+    const int afmt = plan->act_fmt();
+    // f24 buffers: the lo plane of a buffer follows the hi plane of the WHOLE batch
+    auto lo_of = [&](const Layer& B) -> unsigned char* {
+        return B.out_fmt == FMT_F24 && B.slot >= 0 ? base[B.slot] + f24_plane_bytes((size_t)N * B.H * B.W * B.C) : nullptr;
+    };
     const void* in_nhwc = nullptr;
+    const unsigned char* in_nhwc_lo = nullptr;
     if (plan->input_slot >= 0) {
-        int rc = launch_nchw_to_nhwc(x, base[plan->input_slot], af32, N, plan->in_c, plan->in_h, plan->in_w, st);
+        unsigned char* ilo = afmt == FMT_F24 ? base[plan->input_slot] + f24_plane_bytes((size_t)N * plan->in_h * plan->in_w * plan->in_c) : nullptr;
+        int rc = launch_nchw_to_nhwc(x, base[plan->input_slot], ilo, afmt, N, plan->in_c, plan->in_h, plan->in_w, st);
         if (rc) return rc;
         in_nhwc = base[plan->input_slot];
+        in_nhwc_lo = ilo;
     }
     const int nl = (int)plan->layers.size();
     if (events) FR_HIP_CHECK(hipEventRecord(events[0], st));
@@ -538,25 +553,29 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
             continue;
         }
         void* y = (last && L.kind == K_LINEAR) ? (void*)out : (void*)base[L.slot];
+        unsigned char* y_lo = lo_of(L);
         const void* xin = nullptr;
+        const unsigned char* xin_lo = nullptr;
         const float* se = nullptr;
-        if (L.src < 0) xin = in_nhwc;
+        if (L.src < 0) { xin = in_nhwc; xin_lo = in_nhwc_lo; }
         else if (plan->layers[L.src].kind == K_SE) {
             const Layer& S = plan->layers[L.src];
             xin = base[plan->layers[S.src].slot];
+            xin_lo = lo_of(plan->layers[S.src]);
             se = reinterpret_cast<const float*>(base[S.slot]);
-        } else xin = base[plan->layers[L.src].slot];
+        } else { xin = base[plan->layers[L.src].slot]; xin_lo = lo_of(plan->layers[L.src]); }
         const void* res = L.residual >= 0 ? base[plan->layers[L.residual].slot] : nullptr;
+        const unsigned char* res_lo = L.residual >= 0 ? lo_of(plan->layers[L.residual]) : nullptr;
         int rc = FR_OK;
         switch (L.kind) {
             case K_STEM: {
                 StemArgs a{};
                 a.x = x; a.w = L.w_packed;
-                a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act};
+                a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act, y_lo, res_lo};
                 a.N = N; a.H = L.inH; a.W = L.inW; a.Ho = L.H; a.Wo = L.W; a.stride = L.stride; a.NT = L.NT;
                 a.zeros = plan->zeros;
                 if (x_u8) { a.x8 = static_cast<const unsigned char*>(xv); a.lut = plan->u8_lut; }
-                rc = launch_stem(L.out_f32, a, st);
+                rc = launch_stem(L.out_fmt, a, st);
                 break;
             }
             case K_CONV3: {
@@ -573,6 +592,7 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
                     const Layer& D = plan->layers[L.fuse_src];
                     DwArgs a{};
                     a.x = L.fuse_src2 >= 0 ? nullptr : (D.src < 0 ? in_nhwc : (const void*)base[plan->layers[D.src].slot]);
+                    a.x_lo = L.fuse_src2 >= 0 ? nullptr : (D.src < 0 ? in_nhwc_lo : (const unsigned char*)lo_of(plan->layers[D.src]));
                     a.w = D.w_f32; a.bias = D.bias; a.slope = D.slope; a.y = nullptr;
                     a.N = N; a.H = D.inH; a.W = D.inW; a.C = D.C; a.Ho = D.H; a.Wo = D.W; a.pad = D.pad; a.act = D.act;
                     a.zeros = plan->zeros;
@@ -580,9 +600,10 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
                     if (L.fuse_src2 >= 0) {
                         const Layer& E = plan->layers[L.fuse_src2];
                         ex.xin = E.src < 0 ? in_nhwc : (const void*)base[plan->layers[E.src].slot];
+                        ex.xin_lo = E.src < 0 ? in_nhwc_lo : (const unsigned char*)lo_of(plan->layers[E.src]);
                         ex.we = E.w_packed; ex.bias = E.bias; ex.slope = E.slope; ex.act = E.act; ex.Cin = E.K;
                     }
-                    rc = launch_dwp(af32, D.k, D.stride, a, L.w_packed, EpiArgs{L.bias, L.slope, res, y, L.cout, L.act},
+                    rc = launch_dwp(afmt, D.k, D.stride, a, L.w_packed, EpiArgs{L.bias, L.slope, res, y, L.cout, L.act, y_lo, res_lo},
                                     L.fuse_src2 >= 0 ? &ex : nullptr, st);
                     break;
                 }
@@ -595,25 +616,25 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
                     break;
                 }
                 PwArgs a{};
-                a.x = xin; a.w = L.w_packed; a.se = se;
-                a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act};
+                a.x = xin; a.x_lo = xin_lo; a.w = L.w_packed; a.se = se;
+                a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act, y_lo, res_lo};
                 a.M = L.kind == K_PW ? (long)N * L.H * L.W : (long)N;
                 a.K = L.K; a.KS = L.KS; a.NT = L.NT; a.HW = L.H * L.W; a.chunk_ks = L.chunk_ks;
-                rc = L.kind == K_LINEAR ? launch_fc(L.in_f32, a, st) : launch_pw(L.in_f32, L.out_f32, a, st);
+                rc = L.kind == K_LINEAR ? launch_fc(L.in_f32, a, st) : launch_pw(L.in_fmt, L.out_fmt, a, st);
                 break;
             }
             case K_DW: {
                 DwArgs a{};
-                a.x = xin; a.w = L.w_f32; a.bias = L.bias; a.slope = L.slope; a.y = y;
+                a.x = xin; a.x_lo = xin_lo; a.y_lo = y_lo; a.w = L.w_f32; a.bias = L.bias; a.slope = L.slope; a.y = y;
                 a.N = N; a.H = L.inH; a.W = L.inW; a.C = L.C; a.Ho = L.H; a.Wo = L.W; a.pad = L.pad; a.act = L.act;
                 a.zeros = plan->zeros;
                 if (L.slot_partial >= 0) { a.pool = reinterpret_cast<float*>(base[L.slot_partial]); a.pool_tiles = L.pool_tiles; }
-                rc = launch_dw(L.in_f32, L.k, L.stride, a, st);
+                rc = launch_dw(L.in_fmt, L.k, L.stride, a, st);
                 break;
             }
             case K_GDW: {
-                ReduceArgs a{xin, L.w_f32, L.bias, reinterpret_cast<float*>(y), N, L.inH * L.inW, L.C};
-                rc = launch_reduce(L.in_f32, a, st);
+                ReduceArgs a{xin, xin_lo, L.w_f32, L.bias, reinterpret_cast<float*>(y), N, L.inH * L.inW, L.C};
+                rc = launch_reduce(L.in_fmt, a, st);
                 break;
             }
             case K_SE: {
@@ -625,11 +646,11 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
                 // operand load was slower there: 0.030 vs 0.015 ms for the 28x28 layer with 49 tiles)
                 const bool partials = D.slot_partial >= 0 && D.pool_tiles <= 8;
                 if (D.slot_partial >= 0 && !partials) {
-                    ReduceArgs r{base[D.slot_partial], nullptr, nullptr, pool, N, D.pool_tiles, L.C, 1.f / (float)(L.H * L.W)};
-                    rc = launch_reduce(true, r, st);
+                    ReduceArgs r{base[D.slot_partial], nullptr, nullptr, nullptr, pool, N, D.pool_tiles, L.C, 1.f / (float)(L.H * L.W)};
+                    rc = launch_reduce(FMT_F32, r, st);
                 } else if (!partials) {
-                    ReduceArgs r{xin, nullptr, nullptr, pool, N, L.H * L.W, L.C, 0.f};
-                    rc = launch_reduce(L.in_f32, r, st);
+                    ReduceArgs r{xin, xin_lo, nullptr, nullptr, pool, N, L.H * L.W, L.C, 0.f};
+                    rc = launch_reduce(L.in_fmt, r, st);
                 }
                 if (rc) break;
                 PwArgs a{};
@@ -655,13 +676,13 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
             } else if (L.kind == K_LINEAR || L.kind == K_GDW) {
                 if (y != (void*)tap_out) FR_HIP_CHECK(hipMemcpyAsync(tap_out, y, (size_t)N * L.C * 4, hipMemcpyDeviceToDevice, st));
             } else {
-                rc = launch_nhwc_to_nchw(y, L.out_f32, tap_out, N, L.C, L.H, L.W, st);
+                rc = launch_nhwc_to_nchw(y, y_lo, L.out_fmt, tap_out, N, L.C, L.H, L.W, st);
                 if (rc) return rc;
             }
         }
         if (last && L.kind != K_LINEAR) {
             if (L.kind == K_GDW || L.kind == K_SE) FR_HIP_CHECK(hipMemcpyAsync(out, y, (size_t)N * L.C * 4, hipMemcpyDeviceToDevice, st));
-            else { rc = launch_nhwc_to_nchw(y, L.out_f32, out, N, L.C, L.H, L.W, st); if (rc) return rc; }
+            else { rc = launch_nhwc_to_nchw(y, y_lo, L.out_fmt, out, N, L.C, L.H, L.W, st); if (rc) return rc; }
         }
         if (events) FR_HIP_CHECK(hipEventRecord(events[i + 1], st));
     }
@@ -711,7 +732,7 @@ extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char**
         *name = "dwp_kernel";
     } else if (L.kind == K_PW) {
         const bool se = L.src >= 0 && plan->layers[L.src].kind == K_SE;
-        *name = pw_kernel_name(L.in_f32, L.out_f32, L.K, L.cout, se, L.H * L.W);
+        *name = pw_kernel_name(L.in_fmt, L.out_fmt, L.K, L.cout, se, L.H * L.W);
     } else if (L.kind == K_CONV3 && L.in_f32) {
         *name = "conv_gemm_kernel";
     } else if (L.kind == K_CONV3 && L.conv_halo) {

@@ -33,8 +33,13 @@ typedef enum fr_status {
 /* Activation storage / arithmetic mode of a plan.
  * FR_PREC_BF16: activations stored bf16, single bf16 MFMA pass, fp32 accumulate + fp32 epilogue.
  * FR_PREC_F32 : activations stored fp32; GEMM operands split hi+lo bf16, three MFMA passes
- *               (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo), fp32 accumulate (~16 mantissa bits). */
-typedef enum fr_precision { FR_PREC_BF16 = 0, FR_PREC_F32 = 1 } fr_precision;
+ *               (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo), fp32 accumulate (~16 mantissa bits).
+ * FR_PREC_F24 : the arithmetic of FR_PREC_F32 with activations STORED as the top 24 bits of the fp32 pattern (16
+ *               significant bits -- what the split operands carry anyway), rounded to nearest, in two planes per buffer: a
+ *               bf16 plane (the truncated top 16 bits, directly the hi MFMA operand) and a byte plane (the next 8 bits).
+ *               3 bytes per element instead of 4 on a byte-bound path.  Depthwise-separable families only (MobileNetV1 /
+ *               V2 / V3): a plan with a dense 3x3 conv fails with FR_ERR_UNSUPPORTED. */
+typedef enum fr_precision { FR_PREC_BF16 = 0, FR_PREC_F32 = 1, FR_PREC_F24 = 2 } fr_precision;
 /* OR into `precision`: keep every layer a separate launch (no expand->depthwise fusion), so that
  * fr_embed_tap can observe every intermediate tensor. */
 #define FR_PLAN_NO_FUSE 0x100
