@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 M=$1; B=$2; P=${3:-bf16}
 mkdir -p $R/gpurun_out/tr_f_${M}_$P $R/gpurun_out/tr_w_${M}_$P
-A="--model $M --batch $B --precision $P --steps 3 --warmup 1 --no-search --no-cpu-baseline --no-layer-profile --no-modes --no-sphere64"
+A="--model $M --batch $B --precision $P --steps 3 --warmup 1 --no-search --no-cpu-baseline --no-layer-profile --no-modes --no-sphere64 --no-pairs"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/tr_f_${M}_$P -- python3 $R/bench.py $A > /dev/null 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/tr_w_${M}_$P -- python3 $R/bench.py $A > /dev/null 2>&1
 echo done $M $P
