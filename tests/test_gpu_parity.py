@@ -1143,3 +1143,53 @@ def test_pair_verification_at_config0_size_by_properties(tmp_path, golden_dir):
     assert np.abs(o - sims[sample]).max() <= 1e-3
     far = np.abs(o - 0.35) > 1e-3
     assert np.array_equal(osc.decide(sims[sample])[far], osc.decide(o)[far])
+
+
+@pytest.mark.parametrize("ascending", [True, False])
+def test_topk_search_parity_on_score_ordered_gallery(ascending):
+    """The insertion path that random galleries almost never take: a gallery whose score against
+    EVERY query rises (or falls) steadily with the row index -- rows = cos(t) u + sin(t) w with t monotone in the row,
+    queries = u plus a little noise -- so that with ascending order every 64-row tile beats the running top-5 of every
+    lane and the per-lane lists are rewritten on every tile.  Against the oracle's fp32 top-k on the same bf16 rows:
+    scores within 1e-3, indices identical wherever neighbouring scores differ by more than 2e-4, and the three kernel
+    forms agree bit for bit.  (The RATE on such a gallery is 0.5x the random one: profiles/r02_search_adversarial_*.json.)"""
+    G, Q, k = 40_000, 200, 5
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    u = torch.randn(512, generator=gen); u = u / u.norm()
+    w = torch.randn(512, generator=gen); w = w - (w @ u) * u; w = w / w.norm()
+    r = torch.arange(G, dtype=torch.float64) / G
+    score = ((r if ascending else 1 - r) * 0.95)
+    x = score.float()[:, None] * u[None] + torch.sqrt(1 - score * score).float()[:, None] * w[None]
+    x = x + torch.randn((G, 512), generator=gen) * (0.02 / 512 ** 0.5)                 # breaks exact ties between neighbours
+    qx = u[None] + torch.randn((Q, 512), generator=gen) * (0.05 / 512 ** 0.5)
+    g = fr.search.normalize_rows_bf16(x.to(DEV))
+    q = fr.search.normalize_rows_bf16(qx.to(DEV))
+    s, i = fr.search.Matcher(g, k=k).search(q)
+    gf = osr.bf16_bits_to_f32(g.view(torch.int16).cpu().numpy().view(np.uint16))
+    qf = osr.bf16_bits_to_f32(q.view(torch.int16).cpu().numpy().view(np.uint16))
+    os_, oi, _ = osr.topk_cosine(qf, gf, k)
+    s_, i_ = s.cpu().numpy(), i.cpu().numpy()
+    assert np.abs(s_ - os_).max() <= 1e-3
+    assert (np.diff(s_, axis=1) <= 0).all() and (i_ >= 0).all() and (i_ < G).all()
+    full = qf.astype(np.float64) @ gf.astype(np.float64).T / (np.linalg.norm(qf, axis=1)[:, None] * np.linalg.norm(gf, axis=1)[None])
+    srt = -np.sort(-full, axis=1)[:, :k + 1]
+    clear = (srt[:, :-1] - srt[:, 1:]) > 2e-4                                          # rank e is separated from rank e + 1 ...
+    clear[:, 1:] &= clear[:, :-1]                                                      # ... and from rank e - 1
+    assert clear.sum() > Q                                                            # the comparison is not vacuous
+    assert np.array_equal(i_[clear], oi[clear])
+    if ascending:
+        assert (i_ > G - 3000).all()                                                   # the winners sit at the end: lists rewritten all the way
+    import os as _os
+    old = {v: _os.environ.get(v) for v in ("FR_SEARCH_MFMA", "FR_SEARCH_RQ")}
+    try:
+        _os.environ["FR_SEARCH_MFMA"] = "32"
+        s1, i1 = fr.search.Matcher(g, k=k).search(q)
+        _os.environ["FR_SEARCH_RQ"] = "0"
+        s0, i0 = fr.search.Matcher(g, k=k).search(q)
+    finally:
+        for v, val in old.items():
+            if val is None:
+                _os.environ.pop(v, None)
+            else:
+                _os.environ[v] = val
+    assert torch.equal(i1, i) and torch.equal(s1, s) and torch.equal(i0, i) and torch.equal(s0, s)
