@@ -1175,8 +1175,12 @@ def test_topk_search_parity_on_score_ordered_gallery(ascending):
     srt = -np.sort(-full, axis=1)[:, :k + 1]
     clear = (srt[:, :-1] - srt[:, 1:]) > 2e-4                                          # rank e is separated from rank e + 1 ...
     clear[:, 1:] &= clear[:, :-1]                                                      # ... and from rank e - 1
-    assert clear.sum() > Q                                                            # the comparison is not vacuous
     assert np.array_equal(i_[clear], oi[clear])
+    # where neighbours are closer than that (a steady trend of 2e-5 per row): every returned row is a legitimate member
+    # of the top k within the score tolerance, and the rows of a query are distinct
+    got_true = np.take_along_axis(full, i_, axis=1)
+    assert (got_true >= srt[:, k - 1:k] - 1e-3).all() and (np.abs(got_true - s_) <= 1e-3).all()
+    assert (np.diff(np.sort(i_, axis=1), axis=1) > 0).all()
     if ascending:
         assert (i_ > G - 3000).all()                                                   # the winners sit at the end: lists rewritten all the way
     import os as _os
