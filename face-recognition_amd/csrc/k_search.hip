@@ -30,6 +30,7 @@ struct SearchArgs {
     long tiles_per_split;                // 128-row gallery tiles per split
     float* part_s; int* part_i;          // [nsplit][SEARCH_LISTS][Qpad][k]
     long Qpad;
+    int walk;                            // resident-query kernels: 1 = strided tile walk (rq_tile_stride), 0 = in index order
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -262,6 +263,25 @@ __global__ void topk_select_kernel(const float* s, const TI* idx, int nlists, lo
 // per tile (64 MFMAs per wave) instead of one per K slice (16).
 // Selection as in search_kernel: a lane owns one query and sees 16 of the 32 rows of each accumulator tile (its
 // half h), so there are 2 candidate lists per query and split.
+#define RQ_WALK_GRP 16                   // tiles per group of the strided walk (below)
+
+// Tile visiting order of the resident-query kernels: tile j of a split is tile_begin + (j * S mod T) with S ~ 0.618 T,
+// coprime with T (a low-discrepancy walk over the split).  On a gallery whose scores TREND with the row index -- e.g.
+// rows appended in order of quality, a gallery sorted by similarity to a cluster centre -- an in-order walk makes every
+// tile beat the running top-k of every lane (the insertion code then runs on every tile: measured 2.0x slower,
+// profiles/r02_search_adversarial_10M_x_65536.json); the strided walk samples the whole range in its first tiles, so the
+// thresholds are high from the start and insertions die out as on random data.  The per-lane lists are then ordered by
+// (score desc, index asc) explicitly, because "first seen wins" no longer means "lower index wins".
+FR_DEV long rq_tile_stride(long T) {
+    if (T < 3) return 1;
+    long s = (long)((double)T * 0.6180339887498949);
+    if (s < 1) s = 1;
+    for (;; ++s) {
+        long x = s, y = T;
+        while (y) { const long t = x % y; x = y; y = t; }
+        if (x == 1) return s;
+    }
+}
 #define RQ_QB 256                        // queries per block
 #define RQ_GT 64                         // gallery rows per tile
 #define RQ_TILE_BYTES (RQ_GT * SEARCH_D * 2)
@@ -296,7 +316,16 @@ __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(smem + buf * RQ_TILE_BYTES + r * 1024), 16, 0, 0);
         }
     };
-    if (tile_begin < tile_end) stage(tile_begin, 0);
+    const int T = (int)(tile_end - tile_begin);
+    const int NG = (T + RQ_WALK_GRP - 1) / RQ_WALK_GRP;
+    const int S = a.walk ? (int)rq_tile_stride(NG) : 1;
+    auto walk_next = [&](int p_) {                          // see search_rq16_kernel
+        int g = p_ / RQ_WALK_GRP, w = p_ % RQ_WALK_GRP + 1;
+        if (w == RQ_WALK_GRP || g * RQ_WALK_GRP + w >= T) { w = 0; g += S; if (g >= NG) g -= NG; }
+        return g * RQ_WALK_GRP + w;
+    };
+    int p0 = 0, p1 = T > 1 ? walk_next(0) : 0, p2 = T > 2 ? walk_next(p1) : 0;
+    if (tile_begin < tile_end) stage(tile_begin + p0, 0);
 
     // this lane's query (column p of the wave's 32) as B fragments of the 32 k-steps
     bf16x8 bq[32];
@@ -329,7 +358,7 @@ __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
     // Order of a tile: MFMAs -> wait for the next tile's DMA + barrier -> request the tile after next into the
     // buffer just finished -> request the first A fragments of the next tile -> selection of this tile (its VALU
     // work covers the barrier skew and the latency of those first reads) -> next tile.
-    if (tile_begin + 1 < tile_end) stage(tile_begin + 1, 1);
+    if (T > 1) stage(tile_begin + p1, 1);
 #pragma unroll
     for (int j = 0; j < 8; ++j) ka[j] = lds0 + (abase[0] ^ (j << 5));
     if (tile_begin < tile_end) {
@@ -338,7 +367,8 @@ __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
     }
     int buf = 0;
 #pragma unroll 1
-    for (long tile = tile_begin; tile < tile_end; ++tile) {
+    for (int tj = 0; tj < T; ++tj) {
+        const long tile = tile_begin + p0;
         // A fragments are read in groups of RQ_GRP k-steps, one group ahead of the MFMAs that use them.  The reads
         // and their waits are inline asm: through the compiler, every second group waited with lgkmcnt(0) right
         // after the NEXT group's reads had been issued (a full LDS round trip exposed per 8 MFMAs).  LDS reads
@@ -366,13 +396,14 @@ __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
         group(std::integral_constant<int, 12>{}); group(std::integral_constant<int, 13>{}); group(std::integral_constant<int, 14>{}); group(std::integral_constant<int, 15>{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's rows of the next tile have landed
         __syncthreads();                                         // ... everyone's; and everyone is done reading this tile
-        if (tile + 2 < tile_end) stage(tile + 2, buf);
-        if (tile + 1 < tile_end) {
+        if (tj + 2 < T) stage(tile_begin + p2, buf);
+        if (tj + 1 < T) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) ka[j] = lds0 + (buf ^ 1) * RQ_TILE_BYTES + (abase[0] ^ (j << 5));
             rd(std::integral_constant<int, 0>{}, ka[0], af[0][0][0], af[0][0][1]);
             rd(std::integral_constant<int, 1>{}, ka[1], af[0][1][0], af[0][1][1]);
         }
+        p0 = p1; p1 = p2; p2 = walk_next(p2);
         // ---- selection: accumulator rows = gallery rows tile*64 + i*32 + (r&3) + 8*(r>>2) + 4h
         const long gb = tile * RQ_GT;
         const bool partial = gb + RQ_GT > a.G;
@@ -381,21 +412,21 @@ __global__ __launch_bounds__(512, 1) void search_rq_kernel(SearchArgs a) {
             if (partial) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (gb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= a.G) acc[i][r] = -INFINITY;
+                    if (gb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= a.G) acc[i][r] = __builtin_nanf("");
             }
             float mx = acc[i][0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][r]);
-            if (__any(mx > ts[KK - 1])) {
+            if (__any(mx >= ts[KK - 1])) {
                 const int g0 = (int)gb + i * 32 + 4 * h;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float sc = acc[i][r];
-                    if (sc > ts[KK - 1]) {
+                    if (sc >= ts[KK - 1]) {                  // (score desc, index asc): see search_rq16_kernel; a masked row is NaN
                         int gi = g0 + (r & 3) + 8 * (r >> 2);
 #pragma unroll
                         for (int e = 0; e < KK; ++e) {
-                            if (sc > ts[e]) {
+                            if (sc > ts[e] || (sc == ts[e] && gi < ti[e])) {
                                 const float t = ts[e]; ts[e] = sc; sc = t;
                                 const int u = ti[e]; ti[e] = gi; gi = u;
                             }
@@ -456,7 +487,18 @@ __global__ __launch_bounds__(512, 1) void search_rq16_kernel(SearchArgs a) {
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(smem + buf * RQ_TILE_BYTES + r * 1024), 16, 0, 0);
         }
     };
-    if (tile_begin < tile_end) stage(tile_begin, 0);
+    // the walk strides over GROUPS of RQ_WALK_GRP consecutive tiles (1 MB of gallery): a tile-by-tile stride cost 3 % on
+    // random data (every 64-KB tile in another page), groups cost nothing and sample a trend just as well
+    const int T = (int)(tile_end - tile_begin);
+    const int NG = (T + RQ_WALK_GRP - 1) / RQ_WALK_GRP;
+    const int S = a.walk ? (int)rq_tile_stride(NG) : 1;
+    auto walk_next = [&](int p) {                           // p = group * RQ_WALK_GRP + tile within the group
+        int g = p / RQ_WALK_GRP, w = p % RQ_WALK_GRP + 1;
+        if (w == RQ_WALK_GRP || g * RQ_WALK_GRP + w >= T) { w = 0; g += S; if (g >= NG) g -= NG; }
+        return g * RQ_WALK_GRP + w;
+    };
+    int p0 = 0, p1 = T > 1 ? walk_next(0) : 0, p2 = T > 2 ? walk_next(p1) : 0;   // current, next and after-next tile
+    if (tile_begin < tile_end) stage(tile_begin + p0, 0);
 
     // B fragments of this lane's two queries (column c16 of column blocks 0 and 1): k = 32 s + 8 kg + j
     bf16x8 bq[2][16];
@@ -488,13 +530,14 @@ __global__ __launch_bounds__(512, 1) void search_rq16_kernel(SearchArgs a) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d2) : "v"(addr), "n"((s_ >> 2) * 256 + 32768) : "memory");
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d3) : "v"(addr), "n"((s_ >> 2) * 256 + 49152) : "memory");
     };
-    if (tile_begin + 1 < tile_end) stage(tile_begin + 1, 1);
+    if (T > 1) stage(tile_begin + p1, 1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) ka[j] = lds0 + (abase ^ (j << 6));
     if (tile_begin < tile_end) rd4(std::integral_constant<int, 0>{}, ka[0], af[0][0], af[0][1], af[0][2], af[0][3]);
     int buf = 0;
 #pragma unroll 1
-    for (long tile = tile_begin; tile < tile_end; ++tile) {
+    for (int tj = 0; tj < T; ++tj) {
+        const long tile = tile_begin + p0;
         auto step = [&](auto SC) {
             constexpr int s = decltype(SC)::value;
             if constexpr (s + 1 < 16) {
@@ -515,12 +558,13 @@ __global__ __launch_bounds__(512, 1) void search_rq16_kernel(SearchArgs a) {
         step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's rows of the next tile have landed
         __syncthreads();                                         // ... everyone's; and everyone is done reading this tile
-        if (tile + 2 < tile_end) stage(tile + 2, buf);
-        if (tile + 1 < tile_end) {
+        if (tj + 2 < T) stage(tile_begin + p2, buf);
+        if (tj + 1 < T) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) ka[j] = lds0 + (buf ^ 1) * RQ_TILE_BYTES + (abase ^ (j << 6));
             rd4(std::integral_constant<int, 0>{}, ka[0], af[0][0], af[0][1], af[0][2], af[0][3]);
         }
+        p0 = p1; p1 = p2; p2 = walk_next(p2);
         // ---- selection: accumulator rows = gallery rows tile*64 + rb*16 + 4*kg + r, column = this lane's query of block cb
         const long gb = tile * RQ_GT;
         const bool partial = gb + RQ_GT > a.G;
@@ -531,25 +575,26 @@ __global__ __launch_bounds__(512, 1) void search_rq16_kernel(SearchArgs a) {
                 for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (gb + rb * 16 + 4 * kg + r >= a.G) acc[rb][cb][r] = -INFINITY;
+                        if (gb + rb * 16 + 4 * kg + r >= a.G) acc[rb][cb][r] = __builtin_nanf("");
             }
             float mx = acc[0][cb][0];
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[rb][cb][r]);
-            if (__any(mx > ts[cb][KK - 1])) {
+            if (__any(mx >= ts[cb][KK - 1])) {
                 const int g0 = (int)gb + 4 * kg;
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float sc = acc[rb][cb][r];
-                        if (sc > ts[cb][KK - 1]) {
+                        // (score desc, index asc): tiles are not visited in index order.  A masked row (NaN) never enters.
+                        if (sc >= ts[cb][KK - 1]) {
                             int gi = g0 + rb * 16 + r;
 #pragma unroll
                             for (int e = 0; e < KK; ++e) {
-                                if (sc > ts[cb][e]) {
+                                if (sc > ts[cb][e] || (sc == ts[cb][e] && gi < ti[cb][e])) {
                                     const float t = ts[cb][e]; ts[cb][e] = sc; sc = t;
                                     const int u = ti[cb][e]; ti[cb][e] = gi; gi = u;
                                 }
@@ -680,6 +725,7 @@ static int search_run(const uint16_t* q, const uint16_t* g, int64_t Q, int64_t G
     a.q = reinterpret_cast<const bf16*>(q); a.g = reinterpret_cast<const bf16*>(g);
     a.Q = Q; a.G = G; a.k = k;
     const bool rq = search_use_rq();
+    { const char* w = getenv("FR_SEARCH_WALK"); a.walk = !(w && atoi(w) == 0); }         // tuning / comparison: 0 = tiles in index order
     if (rq) search_geometry_rq(Q, G, &a.nsplit, &a.tiles_per_split, &a.Qpad);
     else search_geometry(Q, G, &a.nsplit, &a.tiles_per_split, &a.Qpad);
     const bool m16 = rq && k <= 5 && search_use_mfma16();      // k = 6..8 would spill registers in the 16x16x32 form

@@ -4,6 +4,8 @@ happens.  This measures it on three galleries of the same size:
   random      the benchmark's synthetic rows (insertions become rare after the first few tiles)
   ascending   every query's score grows with the row index: EVERY tile beats the current top-k of every lane
   descending  the best rows come first: no insertion after the first tiles (best case)
+Round 3: the resident-query kernels walk the tiles of a split in a strided group order (k_search.hip: rq_tile_stride), so
+the three orderings now run at the same rate; FR_SEARCH_WALK=0 restores the in-order walk for comparison.
 Usage: python tools/search_adversarial.py [gallery_rows] [queries] [noise]   -> one JSON line"""
 import json
 import os
