@@ -678,16 +678,7 @@ static int launch_pw_stream_sg(const PwArgs& a, hipStream_t st) {
     if (kIsF24<TOut>) lds += 4 * 32 * (size_t)stage_pitch_lo(SG * 32);
 #define FR_PW_GO(MT_, KSM_) do { FR_BIG_LDS((pw_stream_kernel<TIn, TOut, NTB, MT_, KSM_, SG>), lds); \
         hipLaunchKernelGGL((pw_stream_kernel<TIn, TOut, NTB, MT_, KSM_, SG>), grid, dim3(256), lds, st, a, pg); } while (0)
-    if constexpr (kIsF24<TIn>) {
-        static const int mt24 = getenv("FR_PW_MT24") ? atoi(getenv("FR_PW_MT24")) : 0;     // experiment: pixel tiles per wave in f24 plans
-        if (mt24 == 4 && a.KS <= 2) { grid = dim3(pw_grid_blocks((int)std::min<long>((a.M + 511) / 512, want), ng)); const PwGrid pg4{(int)std::min<long>((a.M + 511) / 512, want), ng}; 
-            FR_BIG_LDS((pw_stream_kernel<TIn, TOut, NTB, 4, 2, SG>), lds); hipLaunchKernelGGL((pw_stream_kernel<TIn, TOut, NTB, 4, 2, SG>), grid, dim3(256), lds, st, a, pg4); }
-        else if (mt24 >= 2 && a.KS > 2 && a.KS <= 4) { grid = dim3(pw_grid_blocks((int)std::min<long>((a.M + 255) / 256, want), ng)); const PwGrid pg2{(int)std::min<long>((a.M + 255) / 256, want), ng};
-            FR_BIG_LDS((pw_stream_kernel<TIn, TOut, NTB, 2, 4, SG>), lds); hipLaunchKernelGGL((pw_stream_kernel<TIn, TOut, NTB, 2, 4, SG>), grid, dim3(256), lds, st, a, pg2); }
-        else if (mt == 2) FR_PW_GO(2, 2);
-        else if (a.KS <= 4) FR_PW_GO(1, 4);
-        else FR_PW_GO(1, 8);
-    } else if constexpr (NS == 2) {
+    if constexpr (NS == 2) {
         if (mt == 2) FR_PW_GO(2, 2);
         else if (a.KS <= 4) FR_PW_GO(1, 4);
         else FR_PW_GO(1, 8);
