@@ -532,18 +532,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_kernel(ConvArgs a, 
 // at ANY row shift -- checked exhaustively over the four ds_read_b128 lane groups); the weight rows of a wave's 64
 // couts are packed so that lane group kg = l >> 4 ends up with couts 16 kg .. 16 kg + 15 of its pixels
 // (plan.hip: pack_conv_weights, halo16 order), which keeps the epilogue's 32-byte NHWC pieces.
-template <typename TOut, int TI, int TJ, int WM, int WN>
+// SPB = K slices per barrier: the weight ring holds two STAGES of SPB consecutive slices (contiguous in the packed
+// weights), one DMA + one barrier per stage.  With SPB = 2 the pixel frame of the next chunk is staged only during
+// iterations whose slices all belong to the current chunk (a stage may straddle a chunk boundary: 9 taps per chunk),
+// so a frame is never written while one of its taps is still being read.  Same accumulation order for every SPB.
+template <typename TOut, int TI, int TJ, int WM, int WN, int SPB>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo16_kernel(ConvArgs a, int RB) {
     constexpr int NW = WM * WN, BN = 32 * TI * WM, BM = 32 * TJ * WN, ROWB = 64;
     static_assert(TI == 2, "a wave owns 64 couts (four 16-row blocks)");
     static_assert((NW == 4 || NW == 8) && (BM == 128 || BM == 256), "4 or 8 waves, 128 or 256 pixels per block");
-    constexpr int A_BYTES = BN * ROWB;
-    constexpr int NA = BN / 16, GA = (NA + NW - 1) / NW;
+    static_assert(SPB == 1 || SPB == 2 || SPB == 3, "slices per barrier");
+    constexpr int A_BYTES = BN * ROWB, S_BYTES = SPB * A_BYTES;
+    constexpr int NA = SPB * BN / 16, GA = (NA + NW - 1) / NW;     // 1-KiB pieces of a stage, pieces per wave
     constexpr int NBI = 2 * TI, NBJ = 2 * TJ;          // 16-row blocks per wave: couts, pixels
+    constexpr int BCALLS = SPB;                        // frame pieces per wave and iteration (see the stage_b calls below)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int B_BYTES = RB * ROWB;
-    unsigned char* const bbase = smem + 2 * A_BYTES;
-    const int zrow = 2 * A_BYTES + 2 * B_BYTES;
+    unsigned char* const bbase = smem + 2 * S_BYTES;
+    const int zrow = 2 * S_BYTES + 2 * B_BYTES;
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c16 = lane & 15, kg = lane >> 4;
@@ -575,11 +581,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo16_kernel(ConvArgs a
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(bbase + (c & 1) * B_BYTES + i * 1024), 16, 0, 0);
         }
     };
-    auto stage_a = [&](int ks) {
+    auto stage_a = [&](int it) {
 #pragma unroll
         for (int j = 0; j < GA; ++j)
             if (NA % NW == 0 || wave + NW * j < NA)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[j] + (long)ks * A_BYTES), (lds_ptr_t)(smem + (ks & 1) * A_BYTES + (wave + NW * j) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[j] + (long)it * S_BYTES), (lds_ptr_t)(smem + (it & 1) * S_BYTES + (wave + NW * j) * 1024), 16, 0, 0);
     };
 
     // per-lane tap validity of the NBJ pixels this lane multiplies (pixel 16 pb + c16 of the wave's range)
@@ -616,33 +622,61 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo16_kernel(ConvArgs a
     stage_a(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int tap = 0, chunk = 0, toff = -W - 1, kx = 0;
-#pragma unroll 1
-    for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) stage_a(ks + 1);
-        if (chunk + 1 < chunks) stage_b(wave + NW * tap, chunk + 1);
-        const unsigned char* ab = smem + (ks & 1) * A_BYTES;
-        const int bb = 2 * A_BYTES + (chunk & 1) * B_BYTES;
-        bf16x8 af[NBI], bfr[NBJ];
-#pragma unroll
-        for (int i = 0; i < NBI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ab + aoff[i]);
+    int tap = 0, chunk = 0, toff = -W - 1, kx = 0, bnext = 0;
+    const int NIT = KS / SPB;                          // host: KS % SPB == 0
+    // LDS addresses of the NBJ pixel fragments of the slice (tap, chunk): shifted row of the frame, or the zero row
+    int baddr[NBJ];
+    auto frag_addresses = [&]() {
+        const int bb = 2 * S_BYTES + (chunk & 1) * B_BYTES;
 #pragma unroll
         for (int j = 0; j < NBJ; ++j) {
             const int r = rcen[j] + toff;
             const int at = bb + r * ROWB + ((kg ^ (((r >> 2) & 1) << 1)) << 4);
-            const int addr = ((bmask[j] >> tap) & 1u) ? at : zrow + (at & 255);
-            bfr[j] = *reinterpret_cast<const bf16x8*>(smem + addr);
+            baddr[j] = ((bmask[j] >> tap) & 1u) ? at : zrow + (at & 255);
         }
+    };
+    frag_addresses();
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
+        if (it + 1 < NIT) stage_a(it + 1);
+        // next chunk's pixel frame: only while every slice of this iteration reads the current chunk's frame
+        if (chunk + 1 < chunks && tap + SPB <= 9) {
 #pragma unroll
-        for (int i = 0; i < NBI; ++i)
+            for (int q = 0; q < BCALLS; ++q) stage_b(wave + NW * (bnext + q), chunk + 1);
+            bnext += BCALLS;
+        }
+        const unsigned char* const ab0 = smem + (it & 1) * S_BYTES;
 #pragma unroll
-            for (int j = 0; j < NBJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int s = 0; s < SPB; ++s) {
+            const unsigned char* ab = ab0 + s * A_BYTES;
+            // all eight fragment reads of the slice first (one exposed LDS round trip per slice instead of the three
+            // the scheduler leaves when it re-uses fragment registers), then the 16 MFMAs back to back with the
+            // address arithmetic of the NEXT slice between them (VALU issue is free beside a 16-cycle MFMA)
+            bf16x8 af[NBI], bfr[NBJ];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(smem + baddr[j]);
+#pragma unroll
+            for (int i = 0; i < NBI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ab + aoff[i]);
+            ++tap; ++toff;
+            if (++kx == 3) { kx = 0; toff += W - 3; }
+            if (tap == 9) { tap = 0; toff = -W - 1; ++chunk; bnext = 0; }
+            __builtin_amdgcn_sched_barrier(0);
+            frag_addresses();
+#pragma unroll
+            for (int i = 0; i < NBI; ++i)
+#pragma unroll
+                for (int j = 0; j < NBJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NBI * NBJ; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // up to three VALU
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        ++tap; ++toff;
-        if (++kx == 3) { kx = 0; toff += W - 3; }
-        if (tap == 9) { tap = 0; toff = -W - 1; ++chunk; }
     }
 
     // lane: pixels 16 j + c16 (j < NBJ), couts 16 kg .. 16 kg + 15 of the wave's 64: value 4 i + r = acc[i][j][r]
@@ -706,14 +740,31 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
         FR_BIG_LDS_ONCE(k, lds);                                                                                        \
         hipLaunchKernelGGL(k, g, dim3(64 * WM_ * WN_), lds, st, a, rbm);                                                \
     } while (0)
+#define FR_CONV_HALO16_LAUNCH1(TI_, TJ_, WM_, WN_, SPB_)                                                                \
+    do {                                                                                                                \
+        auto k = conv_halo16_kernel<bf16, TI_, TJ_, WM_, WN_, SPB_>;                                                    \
+        FR_BIG_LDS_ONCE(k, lds16);                                                                                      \
+        hipLaunchKernelGGL(k, g, dim3(64 * WM_ * WN_), lds16, st, a, rbm);                                              \
+    } while (0)
 #define FR_CONV_HALO16_LAUNCH(TI_, TJ_, WM_, WN_)                                                                       \
     do {                                                                                                                \
-        auto k = conv_halo16_kernel<bf16, TI_, TJ_, WM_, WN_>;                                                          \
-        FR_BIG_LDS_ONCE(k, lds);                                                                                        \
-        hipLaunchKernelGGL(k, g, dim3(64 * WM_ * WN_), lds, st, a, rbm);                                                \
+        if (spb == 3) FR_CONV_HALO16_LAUNCH1(TI_, TJ_, WM_, WN_, 3);                                                    \
+        else if (spb == 2) FR_CONV_HALO16_LAUNCH1(TI_, TJ_, WM_, WN_, 2);                                               \
+        else FR_CONV_HALO16_LAUNCH1(TI_, TJ_, WM_, WN_, 1);                                                             \
     } while (0)
                 if (a.halo == 2) {                      // weights packed in the 16x16x32 row order (bf16 output only)
                     if constexpr (std::is_same<TOut, bf16>::value) {
+                        // slices per barrier: the largest of FR_CONV_SPB (default 2) .. 1 that divides the slice count,
+                        // whose frame pieces fit the staging schedule and that keeps two blocks per CU (<= 80 KB)
+                        static const int env_spb = [] { const char* s = getenv("FR_CONV_SPB"); return s ? atoi(s) : 2; }();
+                        const int ks = 9 * (a.Cin / 32), nw = bm == 256 ? 8 : 4;
+                        int spb = std::min(std::max(env_spb, 1), 3);
+                        size_t lds16 = 0;
+                        for (;; --spb) {
+                            lds16 = std::max(2 * (size_t)spb * bn * 64 + 2 * (size_t)rbm * 64 + 256, (size_t)bm * (bn * 2 + 16));
+                            const int pieces = (spb == 2 ? 4 : 9 / spb) * spb * nw;
+                            if (spb == 1 || (ks % spb == 0 && lds16 <= 80 * 1024 && (rbm + 15) / 16 <= pieces)) break;
+                        }
                         if (bm == 256) { if (bn == 128) FR_CONV_HALO16_LAUNCH(2, 2, 2, 4); else FR_CONV_HALO16_LAUNCH(2, 1, 1, 8); }
                         else { if (bn == 128) FR_CONV_HALO16_LAUNCH(2, 2, 2, 2); else FR_CONV_HALO16_LAUNCH(2, 1, 1, 4); }
                         FR_LAUNCH_CHECK("conv_halo16_kernel");
@@ -725,6 +776,7 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
                 if (bm == 256) { if (bn == 128) FR_CONV_HALO_LAUNCH(2, 2, 2, 4); else FR_CONV_HALO_LAUNCH(2, 1, 1, 8); }
                 else { if (bn == 128) FR_CONV_HALO_LAUNCH(2, 2, 2, 2); else FR_CONV_HALO_LAUNCH(2, 1, 1, 4); }
 #undef FR_CONV_HALO16_LAUNCH
+#undef FR_CONV_HALO16_LAUNCH1
 #undef FR_CONV_HALO_LAUNCH
                 FR_LAUNCH_CHECK("conv_halo_kernel");
                 return FR_OK;
