@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_kernel(ConvArgs a, 
 // iterations whose slices all belong to the current chunk (a stage may straddle a chunk boundary: 9 taps per chunk),
 // so a frame is never written while one of its taps is still being read.  Same accumulation order for every SPB.
 template <typename TOut, int TI, int TJ, int WM, int WN, int SPB>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo16_kernel(ConvArgs a, int RB) {
+__global__ __launch_bounds__(64 * WM * WN, 4) void conv_halo16_kernel(ConvArgs a, int RB) {   // 4 waves per SIMD: <= 128 VGPRs
     constexpr int NW = WM * WN, BN = 32 * TI * WM, BM = 32 * TJ * WN, ROWB = 64;
     static_assert(TI == 2, "a wave owns 64 couts (four 16-row blocks)");
     static_assert((NW == 4 || NW == 8) && (BM == 128 || BM == 256), "4 or 8 waves, 128 or 256 pixels per block");
@@ -679,19 +679,55 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo16_kernel(ConvArgs a
         __syncthreads();
     }
 
-    // lane: pixels 16 j + c16 (j < NBJ), couts 16 kg .. 16 kg + 15 of the wave's 64: value 4 i + r = acc[i][j][r]
+    // lane: pixels 16 j + c16 (j < NBJ), couts 16 kg .. 16 kg + 15 of the wave's 64: value 4 i + r = acc[i][j][r].
+    // Same arithmetic as epilogue_stage (bias, activation, residual, one rounding to bf16), but every global load of
+    // the epilogue is issued up front and unconditionally at a clamped address -- bias and slopes once per lane (they
+    // do not depend on the pixel), the residual rows of two pixels at a time -- instead of 6 dependent round trips
+    // per pixel behind the bounds branches.
     constexpr int PITCH = BN * 2 + 16;
     static_assert(std::is_same<TOut, bf16>::value, "the shared-pixel kernels write bf16");
+    {
+        const int c0 = nt0 * BN + wm * 64 + 16 * kg;
+        const bool ok0 = c0 < a.e.cout, ok1 = c0 + 8 < a.e.cout;
+        const int cs0 = ok0 ? c0 : 0, cs1 = ok1 ? c0 + 8 : 0;
+        const bool prelu = a.e.act == FR_ACT_PRELU;
+        const bf16* const R = reinterpret_cast<const bf16*>(a.e.residual);
+        long mm[NBJ];
 #pragma unroll
-    for (int j = 0; j < NBJ; ++j) {
-        const int row = wn * TJ * 32 + j * 16 + c16;
-        const long m = m0 + row;
-        f32x16 v;
+        for (int j = 0; j < NBJ; ++j) mm[j] = min(m0 + wn * TJ * 32 + j * 16 + c16, a.M - 1) * (long)a.e.cout;
 #pragma unroll
-        for (int i = 0; i < NBI; ++i)
+        for (int g = 0; g < 2; ++g) {                  // couts c0 + 8 g .. + 7 of all NBJ pixels: 32 registers of loads
+            const int cs = g ? cs1 : cs0;
+            f32x4 bs[2], sl[2];
+            u32x4 rr[NBJ];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r];
-        epilogue_stage(v, a.e, m, nt0 * BN + wm * 64 + 16 * kg, m < a.M, smem, PITCH, row, wm * 64 + 16 * kg);
+            for (int q = 0; q < 2; ++q) bs[q] = *reinterpret_cast<const f32x4*>(a.e.bias + cs + 4 * q);
+            if (prelu) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) sl[q] = *reinterpret_cast<const f32x4*>(a.e.slope + cs + 4 * q);
+            }
+            if (R) {
+#pragma unroll
+                for (int j = 0; j < NBJ; ++j) rr[j] = *reinterpret_cast<const u32x4*>(R + mm[j] + cs);
+            }
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j) {
+                const int row = wn * TJ * 32 + j * 16 + c16;
+                Vec8f v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v.v[r] = acc[2 * g][j][r] + bs[0][r]; v.v[4 + r] = acc[2 * g + 1][j][r] + bs[1][r]; }
+                if (prelu) prelu8(v, sl[0], sl[1]);
+                else if (a.e.act != FR_ACT_NONE) act8(v, a.e.act, nullptr);
+                if (R) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v.v[2 * q] += __uint_as_float(rr[j][q] << 16);
+                        v.v[2 * q + 1] += __uint_as_float(rr[j][q] & 0xFFFF0000u);
+                    }
+                }
+                if (m0 + row < a.M && (g ? ok1 : ok0)) stage_put(smem, PITCH, row, wm * 64 + 16 * kg + 8 * g, v);
+            }
+        }
     }
     __syncthreads();
     constexpr int CPR = BN / 8;
