@@ -323,14 +323,58 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
         // gives every lane 16 channels of ONE pixel, i.e. isolated 32-byte pieces in global memory (PMC: 1.45x the
         // algorithmic write bytes); staged as [128 pixels][BN couts], the block writes whole BN*2-byte row segments
         constexpr int PITCH = BN * 2 + 16;
+        // same arithmetic as epilogue_stage; the loads of a cout block (bias, slopes, the residual rows of its TJ
+        // pixels) are issued together and unconditionally at clamped addresses instead of one dependent round trip
+        // after the other behind the bounds branches
+        const bool prelu = a.e.act == FR_ACT_PRELU;
+        const bf16* const R = reinterpret_cast<const bf16*>(a.e.residual);
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int row = (wn * TJ + j) * 32 + p;
-            const long m = m0 + row;
+        for (int i = 0; i < TI; ++i) {
+            const int col = (wm * TI + i) * 32 + 16 * h, c0 = nt0 * BN + col;
+            const bool ok0 = c0 < a.e.cout, ok1 = c0 + 8 < a.e.cout;
+            const int cs0 = ok0 ? c0 : 0, cs1 = ok1 ? c0 + 8 : 0;
+            f32x4 bs[4], sl[4];
+            u32x4 rr[TJ][2];
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
-                epilogue_stage(acc[i][j], a.e, m, nt0 * BN + (wm * TI + i) * 32 + 16 * h, m < a.M, smem, PITCH, row,
-                               (wm * TI + i) * 32 + 16 * h);
+            for (int q = 0; q < 2; ++q) {
+                bs[q] = *reinterpret_cast<const f32x4*>(a.e.bias + cs0 + 4 * q);
+                bs[2 + q] = *reinterpret_cast<const f32x4*>(a.e.bias + cs1 + 4 * q);
+            }
+            if (prelu) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    sl[q] = *reinterpret_cast<const f32x4*>(a.e.slope + cs0 + 4 * q);
+                    sl[2 + q] = *reinterpret_cast<const f32x4*>(a.e.slope + cs1 + 4 * q);
+                }
+            }
+            if (R) {
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const long mm = min(m0 + (wn * TJ + j) * 32 + p, a.M - 1) * (long)a.e.cout;
+                    rr[j][0] = *reinterpret_cast<const u32x4*>(R + mm + cs0);
+                    rr[j][1] = *reinterpret_cast<const u32x4*>(R + mm + cs1);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int row = (wn * TJ + j) * 32 + p;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    Vec8f v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v.v[r] = acc[i][j][8 * g + r] + bs[2 * g][r]; v.v[4 + r] = acc[i][j][8 * g + 4 + r] + bs[2 * g + 1][r]; }
+                    if (prelu) prelu8(v, sl[2 * g], sl[2 * g + 1]);
+                    else if (a.e.act != FR_ACT_NONE) act8(v, a.e.act, nullptr);
+                    if (R) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v.v[2 * q] += __uint_as_float(rr[j][g][q] << 16);
+                            v.v[2 * q + 1] += __uint_as_float(rr[j][g][q] & 0xFFFF0000u);
+                        }
+                    }
+                    if (m0 + row < a.M && (g ? ok1 : ok0)) stage_put(smem, PITCH, row, col + 8 * g, v);
+                }
+            }
         }
         __syncthreads();
         constexpr int CPR = BN / 8;                                   // 16-byte chunks per staged row

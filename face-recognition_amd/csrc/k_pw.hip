@@ -626,6 +626,140 @@ int launch_fc(bool in_f32, const PwArgs& a, hipStream_t st) {
     return FR_OK;
 }
 
+// ---- long-K Linear (the SphereFace fc: 25088 -> 512): split K over the grid --------------------------------------
+// fc_kernel gives one block a 32 x 32 output tile and the whole K: 128 blocks for a 256-image sub-batch, each wave
+// walking 392 k-steps of dependent loads, and every weight tile fetched once per 32 rows (0.076 ms per launch, 2 % of
+// a sphere64 step).  Here a block owns 64 rows x 64 columns and one of S slices of K, its four waves split the slice,
+// keep four k-steps (16 fragment loads) in flight each and reduce through LDS; partial sums [S][M][N] go to a
+// workspace slot and fc_splitk_reduce_kernel adds them in slice order and applies the epilogue.  S and the wave
+// split depend on K only, so a row's result does not depend on the batch it is in.
+template <typename TIn>
+__global__ __launch_bounds__(256) void fc_splitk_kernel(PwArgs a, float* __restrict__ partial, int S) {
+    constexpr int NS = std::is_same<TIn, float>::value ? 2 : 1;
+    __shared__ float red[3][4][16][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int p = lane & 31, h = lane >> 5;
+    const long mb = (long)blockIdx.x * 64;
+    const int t0 = blockIdx.y * 2, z = blockIdx.z;
+    const int ks_z = (a.KS + S - 1) / S, zb = z * ks_z, ze = min(a.KS, zb + ks_z);
+    const int ks_w = (ks_z + 3) >> 2;
+    const int s_begin = zb + wave * ks_w, s_end = min(ze, s_begin + ks_w);
+    const TIn* xrow[2];
+    const bf16x8* W[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xrow[j] = reinterpret_cast<const TIn*>(a.x) + min(mb + 32 * j + p, a.M - 1) * (long)a.K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) W[i] = reinterpret_cast<const bf16x8*>(a.w) + (size_t)min(t0 + i, a.NT - 1) * a.KS * NS * 64 + lane;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int sg = s_begin; sg < s_end; sg += 4) {
+        XFrag<TIn> xf[4][2];
+        bf16x8 wf[4][2][NS];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = sg + q, kk = s * 16 + 8 * h;
+            const int sc = s < s_end ? s : s_end - 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) wf[q][i][sp] = W[i][((size_t)sc * NS + sp) * 64];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (s < s_end && kk < a.K) xf[q][j].load(xrow[j] + kk, nullptr);
+                else xf[q][j].zero();
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (sg + q < s_end) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q][i][0], xf[q][j].hi, acc[i][j], 0, 0, 0);
+                        if constexpr (NS == 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q][i][0], xf[q][j].lo, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q][i][1], xf[q][j].hi, acc[i][j], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave - 1][2 * i + j][r][lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int w = 0; w < 3; ++w)                   // fixed order: deterministic
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += red[w][2 * i + j][r][lane];
+                const long m = mb + 32 * j + p;
+                const int c0 = 32 * (t0 + i) + 16 * h;
+                if (m < a.M && t0 + i < a.NT) {
+                    float* dst = partial + ((size_t)z * a.M + m) * a.e.cout + c0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (c0 + 4 * g < a.e.cout)
+                            *reinterpret_cast<f32x4*>(dst + 4 * g) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                }
+            }
+    }
+}
+
+// y[m][c] = act(sum_z partial[z][m][c] + bias[c]), slices added in order (fp32 output, as epilogue_store<float>)
+__global__ __launch_bounds__(256) void fc_splitk_reduce_kernel(const float* __restrict__ partial, EpiArgs e, long M, int S) {
+    const long n4 = M * (long)(e.cout >> 2);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)(i % (e.cout >> 2)) * 4;
+    const f32x4* src = reinterpret_cast<const f32x4*>(partial) + i;
+    f32x4 v = src[0];
+    for (int z = 1; z < S; ++z) { const f32x4 t = src[(size_t)z * n4]; v += t; }
+    const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + c);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q] + b[q], e.act, 0.f);
+    reinterpret_cast<f32x4*>(e.y)[i] = v;
+}
+
+// K slices of the split-K Linear for a reduction length of K (0: use fc_kernel).  A function of K only.
+int fc_splitk_slices(int K) {
+    static const int env = [] { const char* s = getenv("FR_FC_SPLITK"); return s ? atoi(s) : -1; }();   // tuning: 0 = off
+    if (env == 0 || K < 8192) return 0;
+    return env > 0 ? std::min(env, 32) : 8;
+}
+
+int launch_fc_splitk(bool in_f32, const PwArgs& a, float* partial, int S, hipStream_t st) {
+    if (a.M <= 0 || a.K <= 0 || a.K % 8 || a.e.cout % 8 || a.KS != cdiv(a.K, 16) || a.NT != cdiv(a.e.cout, 32) || a.se || a.e.residual ||
+        a.e.slope || !partial || S < 1 || S > 32 || a.e.cout % 4)
+        FR_FAIL(FR_ERR_ARG, "fc (split K): inconsistent shapes");
+    const long mt = (a.M + 63) / 64;
+    if (mt > 0x7FFFFFFFL || a.NT > 65535) FR_FAIL(FR_ERR_ARG, "fc (split K): grid too large");
+    dim3 grid((unsigned)mt, (unsigned)cdiv(a.NT, 2), (unsigned)S);
+    if (in_f32) hipLaunchKernelGGL((fc_splitk_kernel<float>), grid, dim3(256), 0, st, a, partial, S);
+    else hipLaunchKernelGGL((fc_splitk_kernel<bf16>), grid, dim3(256), 0, st, a, partial, S);
+    FR_LAUNCH_CHECK("fc_splitk_kernel");
+    const long n4 = a.M * (long)(a.e.cout >> 2);
+    hipLaunchKernelGGL(fc_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)partial, a.e, a.M, S);
+    FR_LAUNCH_CHECK("fc_splitk_reduce_kernel");
+    return FR_OK;
+}
+
 void pw_pick_tiling(bool in_f32, int NT, int KS, int* ntb, int* chunk_ks) {
     const int ns = in_f32 ? 2 : 1;
     if (in_f32 && KS <= 8 && !(getenv("FR_PW_F32_STREAM") && atoi(getenv("FR_PW_F32_STREAM")) == 0)) {

@@ -28,6 +28,9 @@ int launch_pw(int in_fmt, int out_fmt, const PwArgs& a, hipStream_t st);
 const char* pw_kernel_name(int in_fmt, int out_fmt, int K, int cout, bool se, int HW);
 // Small-M form (M = batch): SE fc layers, Linear(+BN1d).  fp32 output, no SE scale, no residual.  in_f32: fp32 rows (never f24)
 int launch_fc(bool in_f32, const PwArgs& a, hipStream_t st);
+// long-K Linear: S = fc_splitk_slices(K) > 0 slices of K, partial sums [S][M][cout] fp32 in `partial`, then a reduce launch
+int fc_splitk_slices(int K);
+int launch_fc_splitk(bool in_f32, const PwArgs& a, float* partial, int S, hipStream_t st);
 // LDS bytes per (n-tile, k-step) = 1024 * NS; used by the planner to pick chunk_ks.  wide: fp32-class input (FMT_F32 / FMT_F24)
 void pw_pick_tiling(bool wide, int NT, int KS, int* ntb, int* chunk_ks);
 

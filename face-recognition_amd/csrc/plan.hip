@@ -44,6 +44,7 @@ struct Layer {
     int slot = -1;                        // output slot
     int slot_pool = -1, slot_hidden = -1; // SE extras (fp32 [N,C], [N,S]); slot = scale [N,C]
     int slot_partial = -1, pool_tiles = 0; // depthwise feeding an SE block: per-tile channel sums [N,pool_tiles,C] fp32
+    int splitk = 0;                       // long-K Linear: K slices of fc_splitk_kernel (partial sums in slot_partial); 0 = fc_kernel
     // device parameters
     bf16* w_packed = nullptr;             // GEMM-shaped kernels
     bf16* w_packed2 = nullptr;            // SE fc2
@@ -330,6 +331,7 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
         } else {
             pack_gemm_weights(W, d.cout, K, L.in_f32 ? 2 : 1, packed, &L.KS, &L.NT);
             int ntb; pw_pick_tiling(L.in_f32, L.NT, L.KS, &ntb, &L.chunk_ks);
+            L.splitk = fc_splitk_slices(K);
         }
         rc = upload(pl, packed, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
         rc = upload(pl, padded(shift, cdiv(d.cout, 128) * 128), &L.bias); if (rc) return rc;
@@ -448,6 +450,11 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         } else {
             L.slot = alloc_slot(sizes, busy, layer_out_bytes(L));
             launches += 1;
+            if (L.kind == K_LINEAR && L.splitk > 0) {       // partial sums of the K slices, free again after the layer
+                L.slot_partial = alloc_slot(sizes, busy, (size_t)L.splitk * L.cout * 4);
+                busy[L.slot_partial] = 0;
+                launches += 1;
+            }
             // depthwise -> squeeze-excite: the depthwise kernel also emits per-tile channel sums, so the
             // SE block never re-reads the activation (freed again once the SE layer has run)
             static const bool se_fuse = !(getenv("FR_SE_FUSE") && atoi(getenv("FR_SE_FUSE")) == 0);
@@ -620,7 +627,8 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
                 a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act, y_lo, res_lo};
                 a.M = L.kind == K_PW ? (long)N * L.H * L.W : (long)N;
                 a.K = L.K; a.KS = L.KS; a.NT = L.NT; a.HW = L.H * L.W; a.chunk_ks = L.chunk_ks;
-                rc = L.kind == K_LINEAR ? launch_fc(L.in_f32, a, st) : launch_pw(L.in_fmt, L.out_fmt, a, st);
+                if (L.kind == K_LINEAR && L.splitk > 0) rc = launch_fc_splitk(L.in_f32, a, reinterpret_cast<float*>(base[L.slot_partial]), L.splitk, st);
+                else rc = L.kind == K_LINEAR ? launch_fc(L.in_f32, a, st) : launch_pw(L.in_fmt, L.out_fmt, a, st);
                 break;
             }
             case K_DW: {
@@ -739,6 +747,8 @@ extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char**
         *name = L.conv_halo16 ? "conv_halo16_kernel" : "conv_halo_kernel";
     } else if (L.kind == K_LINEAR && L.via_conv) {
         *name = L.in_f32 ? "conv_gemm_kernel" : "conv_glds_kernel";
+    } else if (L.kind == K_LINEAR && L.splitk > 0) {
+        *name = "fc_splitk_kernel(+reduce)";
     }
     return FR_OK;
 }
