@@ -616,12 +616,12 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_halo16_kernel(ConvArgs a
         wsrc[j] = reinterpret_cast<const unsigned char*>(a.w) + ((size_t)nt0 * KS * BN + 16 * (wave + NW * j) + sub) * ROWB + lc * 16;
     const unsigned char* const X = reinterpret_cast<const unsigned char*>(a.x);
     const unsigned char* const zsrc = reinterpret_cast<const unsigned char*>(a.zeros);
-    const long gbase = m0 - W - 1;
-    const long rowbytes = (long)a.Cin * 2;
+    const int gbase = (int)m0 - W - 1;                  // launcher: M + 256 < 2^31
+    const int rowbytes = a.Cin * 2;
     auto stage_b = [&](int i, int c) {
         if (16 * i < RB) {
-            const long g = gbase + 16 * i + sub;
-            const unsigned char* src = (g >= 0 && g < a.M) ? X + g * rowbytes + (long)c * 64 + lc * 16 : zsrc;
+            const int g = gbase + 16 * i + sub;
+            const unsigned char* src = (g >= 0 && g < (int)a.M) ? X + (long)g * rowbytes + (c * 64 + lc * 16) : zsrc;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(bbase + (c & 1) * B_BYTES + i * 1024), 16, 0, 0);
         }
     };
