@@ -434,6 +434,116 @@ FR_DEV void epilogue_stage_f24(const f32x16& acc, const EpiArgs& e, long m, int 
     }
     *reinterpret_cast<u32x4*>(stage_lo + row * pitch_lo + col0) = lo;
 }
+// The arithmetic of every GEMM-shaped epilogue: v[g] = act(acc + bias) (+ residual) for the lane's channel groups
+// c0 + 8 g .. + 7 (g = 0, 1) of pixel m; ok[g] says whether the group exists (pixel inside M, channels inside cout).
+// Every load is issued up front and unconditionally, at an address clamped into the arrays (row 0, channel 0 for a
+// lane that is out of range; bias and slopes are padded to 32 channels): loads behind per-lane bounds branches cannot
+// be hoisted by the compiler and cost one dependent round trip each (bias, slope, residual, twice per tile).
+// T: storage type of the residual (bf16, float, f24).
+template <typename T>
+FR_DEV void epilogue_values(const f32x16& acc, const EpiArgs& e, long m, int c0, bool m_ok, Vec8f (&v)[2], bool (&ok)[2]) {
+    const long mm = m_ok ? m : 0;
+    int cs[2];
+    f32x4 b[2][2], sl[2][2];
+    Vec8f r[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int c = c0 + 8 * g;
+        ok[g] = m_ok && c < e.cout;
+        cs[g] = c < e.cout ? c : 0;
+        b[g][0] = *reinterpret_cast<const f32x4*>(e.bias + cs[g]);
+        b[g][1] = *reinterpret_cast<const f32x4*>(e.bias + cs[g] + 4);
+    }
+    const bool prelu = e.act == FR_ACT_PRELU;
+    if (prelu) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            sl[g][0] = *reinterpret_cast<const f32x4*>(e.slope + cs[g]);
+            sl[g][1] = *reinterpret_cast<const f32x4*>(e.slope + cs[g] + 4);
+        }
+    }
+    if (e.residual) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const long off = mm * (long)e.cout + cs[g];
+            if constexpr (kIsF24<T>) r[g] = f24_load8(reinterpret_cast<const bf16*>(e.residual) + off, e.residual_lo + mm * (long)f24_lo_pitch(e.cout) + cs[g]);
+            else r[g] = load8(reinterpret_cast<const T*>(e.residual) + off);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[g].v[i] = acc[8 * g + i] + b[g][0][i]; v[g].v[4 + i] = acc[8 * g + 4 + i] + b[g][1][i]; }
+        if (prelu) prelu8(v[g], sl[g][0], sl[g][1]);
+        else if (e.act != FR_ACT_NONE) act8(v[g], e.act, nullptr);
+        if (e.residual) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[g].v[i] += r[g].v[i];
+        }
+    }
+}
+
+// ---- the *_h forms: the same functions on epilogue_values (all loads up front).  Measured per kernel: they pay in
+// pw_proj_kernel and dwp_kernel (-1..2 %), cost occupancy in stem_kernel / pw_gemm_kernel (68 -> 106 VGPRs), so each
+// call site chooses.
+template <typename TOut>
+FR_DEV void epilogue_store_h(const f32x16& acc, const EpiArgs& e, long m, int c0, bool m_ok) {
+    Vec8f v[2];
+    bool ok[2];
+    epilogue_values<TOut>(acc, e, m, c0, m_ok, v, ok);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (!ok[g]) continue;
+        const int c = c0 + 8 * g;
+        const long off = m * (long)e.cout + c;
+        if constexpr (kIsF24<TOut>) f24_store8(reinterpret_cast<bf16*>(e.y) + off, e.y_lo + m * (long)f24_lo_pitch(e.cout) + c, v[g]);
+        else store8(reinterpret_cast<TOut*>(e.y) + off, v[g]);
+    }
+}
+
+// Same arithmetic as epilogue_store, but the bf16 result goes to the wave's LDS staging tile
+// (row = pixel within the tile, col = channel within the staged group) instead of global memory.
+FR_DEV void epilogue_stage_h(const f32x16& acc, const EpiArgs& e, long m, int c0, bool m_ok,
+                           unsigned char* stage, int pitch, int row, int col0) {
+    Vec8f v[2];
+    bool ok[2];
+    epilogue_values<bf16>(acc, e, m, c0, m_ok, v, ok);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+        if (ok[g]) stage_put(stage, pitch, row, col0 + 8 * g, v[g]);
+}
+
+// epilogue_stage for fp32 outputs: same arithmetic as epilogue_store_h<float>, result into the wave's fp32 staging tile.
+FR_DEV void epilogue_stage_f32_h(const f32x16& acc, const EpiArgs& e, long m, int c0, bool m_ok,
+                               unsigned char* stage, int pitch, int row, int col0) {
+    Vec8f v[2];
+    bool ok[2];
+    epilogue_values<float>(acc, e, m, c0, m_ok, v, ok);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+        if (ok[g]) stage_put_f32(stage, pitch, row, col0 + 8 * g, v[g]);
+}
+
+// epilogue_stage for f24 outputs: same arithmetic, the result rounded to f24; the hi halves go to the wave's bf16-shaped
+// staging tile (written back by stage_flush like a bf16 tile), the lo bytes of the lane's 16 channels (16 B) to a second
+// tile at byte column col0 (written back by stage_flush_lo).  A lane whose pixel is out of range writes nothing.
+FR_DEV void epilogue_stage_f24_h(const f32x16& acc, const EpiArgs& e, long m, int c0, bool m_ok,
+                               unsigned char* stage, int pitch, unsigned char* stage_lo, int pitch_lo, int row, int col0) {
+    Vec8f v[2];
+    bool ok[2];
+    epilogue_values<f24>(acc, e, m, c0, m_ok, v, ok);
+    if (!m_ok) return;
+    u32x4 lo = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (!ok[g]) continue;
+        u32x4 h; unsigned l0, l1;
+        f24_encode(v[g], h, l0, l1);
+        *reinterpret_cast<u32x4*>(stage + row * pitch + (col0 + 8 * g) * 2) = h;
+        lo[2 * g] = l0; lo[2 * g + 1] = l1;
+    }
+    *reinterpret_cast<u32x4*>(stage_lo + row * pitch_lo + col0) = lo;
+}
 // rows [0,rows) x ncol channels of the lo staging tile -> the lo plane (row stride lp bytes), whole 16-byte chunks (a
 // trailing half chunk lands in the padding of the 16-byte-padded lo rows)
 __host__ __device__ constexpr int stage_pitch_lo(int row_bytes) { return row_bytes + 16; }

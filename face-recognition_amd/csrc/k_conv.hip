@@ -795,12 +795,17 @@ int conv_halo_rows(int ksize, int stride, int pad, int W, int bk) {
     return rb <= 576 ? rb : 0;                       // 9 taps x 4 waves x 16 rows: a ninth of the range per tap
 }
 
-int conv_block_couts(int cout) { return cout >= 128 ? 128 : 64; }
+// couts per block tile.  Small maps (the 7x7 stage of SphereFace: 49 output pixels per image) take 64-cout tiles:
+// their layers have so few pixel tiles that 128-cout blocks leave the chip at 1-2 waves per SIMD.
+int conv_block_couts(int cout, int out_hw) {
+    static const int small_hw = [] { const char* s = getenv("FR_CONV_BN64_HW"); return s ? atoi(s) : 0; }();   // tuning
+    return cout >= 128 && out_hw > small_hw ? 128 : 64;
+}
 
 template <typename TIn, typename TOut>
 static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     constexpr int NS = std::is_same<TIn, float>::value ? 2 : 1;
-    const int bn = conv_block_couts(a.e.cout);
+    const int bn = conv_block_couts(a.e.cout, a.Ho * a.Wo);
     dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)cdiv(a.e.cout, bn));
     if constexpr (std::is_same<TIn, bf16>::value) {
         if (a.zeros) {

@@ -790,9 +790,9 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
                             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[(s * NS + 1) * 64], xf, acc, 0, 0, 0);
                         }
                     }
-                    if constexpr (F24) epilogue_stage_f24(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, stage_lo, PITCH_LO, p, 32 * tt + 16 * h);
-                    else if constexpr (F32) epilogue_stage_f32(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, p, 32 * tt + 16 * h);
-                    else epilogue_stage(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, p, 32 * tt + 16 * h);
+                    if constexpr (F24) epilogue_stage_f24_h(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, stage_lo, PITCH_LO, p, 32 * tt + 16 * h);
+                    else if constexpr (F32) epilogue_stage_f32_h(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, p, 32 * tt + 16 * h);
+                    else epilogue_stage_h(acc, e2, m, 32 * t + 16 * h, ok, stage, PITCH, p, 32 * tt + 16 * h);
                 }
             }
             // write the staged [32 pixels][<= 64 channels] back: consecutive pixels of a tile row are contiguous

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
         if constexpr (F32) {
 #pragma unroll
             for (int t = 0; t < PJ_NT; ++t)
-                if (t < nt) epilogue_store<T>(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok);
+                if (t < nt) epilogue_store_h<T>(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok);
         } else {
             const long tile0 = m - p, left = a.M - tile0;
 #pragma unroll
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
                 if (tg < nt) {
 #pragma unroll
                     for (int t = tg; t < tg + SG; ++t)
-                        if (t < PJ_NT && t < nt) epilogue_stage(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok, stage, PITCH, p, 32 * (t - tg) + 16 * h);
+                        if (t < PJ_NT && t < nt) epilogue_stage_h(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok, stage, PITCH, p, 32 * (t - tg) + 16 * h);
                     if (left > 0)
                         stage_flush(stage, PITCH, lane, reinterpret_cast<bf16*>(a.e.y) + tile0 * a.e.cout + (t0 + tg) * 32, a.e.cout,
                                     min(SG * 32, min(a.e.cout, (t0 + nt) * 32) - (t0 + tg) * 32), left < 32 ? (int)left : 32);
