@@ -839,11 +839,10 @@ static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     } while (0)
                 if (a.halo == 2) {                      // weights packed in the 16x16x32 row order (bf16 output only)
                     if constexpr (std::is_same<TOut, bf16>::value) {
-                        // slices per barrier: the largest of FR_CONV_SPB (default 2) .. 1 that divides the slice count,
+                        // slices per barrier: the largest of a.spb (the plan's FR_CONV_SPB; default 2) .. 1 that divides the slice count,
                         // whose frame pieces fit the staging schedule and that keeps two blocks per CU (<= 80 KB)
-                        static const int env_spb = [] { const char* s = getenv("FR_CONV_SPB"); return s ? atoi(s) : 2; }();
                         const int ks = 9 * (a.Cin / 32), nw = bm == 256 ? 8 : 4;
-                        int spb = std::min(std::max(env_spb, 1), 3);
+                        int spb = std::min(std::max(a.spb > 0 ? a.spb : 2, 1), 3);
                         size_t lds16 = 0;
                         for (;; --spb) {
                             lds16 = std::max(2 * (size_t)spb * bn * 64 + 2 * (size_t)rbm * 64 + 256, (size_t)bm * (bn * 2 + 16));

@@ -850,6 +850,12 @@ static const DwpTileEntry kDwpTilesF32[] = {
     {88, 24, 28, 3, 1, 24, 4, 28},        // mobilenetv3_small features.3: 0.148 vs 0.202 ms
 };
 
+// spare 16-byte slots per pixel (and half-plane) of a tile that the kernel computes itself (expand form)
+static int dwp_tile_pad() {
+    static const int pad = [] { const char* e = getenv("FR_DWP_PAD"); return e ? std::min(std::max(atoi(e), 0), 4) : 1; }();
+    return pad;
+}
+
 static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int cin, DwpPlan* out) {
     const bool f32 = fmt != FMT_BF16;                     // fp32-class arithmetic: hi + lo planes, fp32 expanded tile
     const bool f24 = fmt == FMT_F24;
@@ -904,7 +910,7 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
         // MFMA lanes (one pixel each) write it without bank conflicts
         // (a tile computed in the kernel is fp32 half-planes for both fp32-class formats; one staged from HBM is in the plan's format)
         const int tfmt = cin ? (f32 ? FMT_F32 : FMT_BF16) : fmt;
-        const size_t tile = dw_lds_bytes(tfmt, k, s, th, tw, CV) + (cin ? (size_t)(IH * IW) * (f32 ? 32 : 16) : 0);
+        const size_t tile = dw_lds_bytes(tfmt, k, s, th, tw, CV) + (cin ? (size_t)dwp_tile_pad() * (IH * IW) * (f32 ? 32 : 16) : 0);
         // the output staging tiles live behind the depthwise result, inside the (by then dead) input tile
         const size_t off_stage = align_up(dwo, 16);
         const size_t off_wp = align_up(std::max(tile, off_stage + stage_bytes), 1024);
@@ -966,7 +972,7 @@ int launch_dwp(int fmt, int k, int stride, DwArgs a, const bf16* wp, const EpiAr
     g.nstrips = a.TW / sw;
     g.nitems = a.TH * g.nstrips * a.CBV;
     g.nunits = g.IH * g.IW * a.CBV * (fmt == FMT_F32 ? 2 : 1);
-    g.PP = ex ? a.CBV + 1 : a.CBV;
+    g.PP = ex ? a.CBV + dwp_tile_pad() : a.CBV;
     g.PPL = (a.CBV + 1) / 2;
     g.tile_bytes = (int)dw_tile_bytes(ex ? (f32 ? FMT_F32 : FMT_BF16) : fmt, g.IH, g.IW, g.PP);
     g.d_cbv = make_div32(a.CBV); g.d_iw = make_div32(g.IW); g.d_ns = make_div32(g.nstrips); g.d_tw = make_div32(a.TW);

@@ -196,14 +196,19 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwArgs a, PwGrid pg) {
 // while chunk c (4 k-steps = 64 input channels) is multiplied, the LDS-DMA of weight chunk c+1
 // into the other LDS buffer and the loads of activation chunk c+1 (and its SE scales) into a
 // second register set are already in flight.  One wait + one barrier per chunk.
-constexpr int PJ_NT = 5;          // n-tiles per block
+constexpr int PJ_NT = 5;          // most n-tiles per block (NTC = 2..5, a template parameter)
 constexpr int PJ_IMGS = 4;        // images a 128-pixel super-tile can span (needs H*W >= 43)
 
 // T = bf16: chunks of 4 k-steps (64 input channels), bf16 output staged through LDS.
 // T = float (fp32 plans, round 2): chunks of 2 k-steps with hi+lo weight fragments (the same 20 KB per buffer), fp32
 // activations split on use, three MFMA passes in pw_gemm_kernel's order (same bits), fp32 output stored directly (these
 // are the narrow outputs of the project convs: <= 160 channels, 64 contiguous bytes per lane).
-template <bool SE, typename T>
+// NTC: n-tiles per block at compile time (round 3).  With a run-time tile count every tile of the multiply sat behind
+// a uniform branch, so each weight fragment was read, waited for and used on its own: two exposed LDS round trips per
+// tile and k-step (fp32: 360 cycles for 96 cycles of MFMA).  With NTC fixed the fragments of all tiles are read
+// up front and the passes run tile-interleaved.  A block whose column group has fewer than NTC tiles multiplies the
+// (never written, never stored) LDS slots of the missing tiles.
+template <bool SE, typename T, int NTC>
 __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
     constexpr bool F32 = kWide<T>;                      // fp32-class arithmetic: fp32 or f24 activations
     constexpr bool F24 = kIsF24<T>;
@@ -213,7 +218,8 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
     constexpr int XU = (F32 && !F24) ? 2 : 1;           // 16-byte units of one lane's 8 input channels (f24: the hi plane's)
     struct Raw { u32x4 x[CK][XU]; unsigned long long xl[F24 ? CK : 1]; };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WBUF = PJ_NT * CK * NS * 1024;
+    static_assert(NTC >= 2 && NTC <= PJ_NT, "2..5 n-tiles per block");
+    constexpr int WBUF = NTC * CK * NS * 1024;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int t0 = blockIdx.y * a.ntg;
@@ -274,9 +280,9 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
             }
         };
 
-        f32x16 acc[PJ_NT];
+        f32x16 acc[NTC];
 #pragma unroll
-        for (int t = 0; t < PJ_NT; ++t)
+        for (int t = 0; t < NTC; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -316,16 +322,22 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
                         xf = __builtin_bit_cast(bf16x8, raw.x[j][0]);
                     }
                     if (!live) { xf = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xl = xf; }
+                    // every accumulator still sees hi.hi, hi.lo, lo.hi in that order (same bits as before)
+                    bf16x8 wh[NTC], wlo[NTC];
 #pragma unroll
-                    for (int t = 0; t < PJ_NT; ++t)
-                        if (t < nt) {
-                            const bf16x8 wh = wb[((t * CK + j) * NS) * 64];
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf, acc[t], 0, 0, 0);
-                            if constexpr (F32) {
-                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[t], 0, 0, 0);
-                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[((t * CK + j) * NS + 1) * 64], xf, acc[t], 0, 0, 0);
-                            }
-                        }
+                    for (int t = 0; t < NTC; ++t) {
+                        wh[t] = wb[((t * CK + j) * NS) * 64];
+                        if constexpr (F32) wlo[t] = wb[((t * CK + j) * NS + 1) * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);     // (the scheduler otherwise sinks the lo fragments to their uses, one wait each)
+#pragma unroll
+                    for (int t = 0; t < NTC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], xf, acc[t], 0, 0, 0);
+                    if constexpr (F32) {
+#pragma unroll
+                        for (int t = 0; t < NTC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], xl, acc[t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < NTC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[t], xf, acc[t], 0, 0, 0);
+                    }
                 }
             }
         };
@@ -349,16 +361,16 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
 
         if constexpr (F32) {
 #pragma unroll
-            for (int t = 0; t < PJ_NT; ++t)
+            for (int t = 0; t < NTC; ++t)
                 if (t < nt) epilogue_store_h<T>(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok);
         } else {
             const long tile0 = m - p, left = a.M - tile0;
 #pragma unroll
-            for (int tg = 0; tg < PJ_NT; tg += SG) {
+            for (int tg = 0; tg < NTC; tg += SG) {
                 if (tg < nt) {
 #pragma unroll
                     for (int t = tg; t < tg + SG; ++t)
-                        if (t < PJ_NT && t < nt) epilogue_stage_h(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok, stage, PITCH, p, 32 * (t - tg) + 16 * h);
+                        if (t < NTC && t < nt) epilogue_stage_h(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok, stage, PITCH, p, 32 * (t - tg) + 16 * h);
                     if (left > 0)
                         stage_flush(stage, PITCH, lane, reinterpret_cast<bf16*>(a.e.y) + tile0 * a.e.cout + (t0 + tg) * 32, a.e.cout,
                                     min(SG * 32, min(a.e.cout, (t0 + nt) * 32) - (t0 + tg) * 32), left < 32 ? (int)left : 32);
@@ -368,20 +380,39 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
     }
 }
 
-template <typename T>
-static int launch_pw_proj(const PwArgs& a, hipStream_t st) {
+template <typename T, int NTC>
+static int launch_pw_proj_n(const PwArgs& a, hipStream_t st) {
     constexpr bool F32 = kWide<T>;
     const long n_super = (a.M + 127) / 128;
     PwArgs b = a;
-    b.ntg = PJ_NT;
+    b.ntg = NTC;
     const int groups = cdiv(a.NT, b.ntg);
     dim3 grid((unsigned)std::min<long>(n_super, 4096), (unsigned)groups);
-    size_t lds = 2 * (size_t)PJ_NT * (F32 ? 2 * 2 : 4) * 1024 + (F32 ? 0 : 4 * 32 * (size_t)stage_pitch(2 * 64));
+    size_t lds = 2 * (size_t)NTC * (F32 ? 2 * 2 : 4) * 1024 + (F32 ? 0 : 4 * 32 * (size_t)stage_pitch(2 * 64));
     if (a.se) lds += (size_t)PJ_IMGS * a.K * 4;
-    if (a.se) { FR_BIG_LDS((pw_proj_kernel<true, T>), lds); hipLaunchKernelGGL((pw_proj_kernel<true, T>), grid, dim3(256), lds, st, b); }
-    else hipLaunchKernelGGL((pw_proj_kernel<false, T>), grid, dim3(256), lds, st, b);
+    if (a.se) { FR_BIG_LDS((pw_proj_kernel<true, T, NTC>), lds); hipLaunchKernelGGL((pw_proj_kernel<true, T, NTC>), grid, dim3(256), lds, st, b); }
+    else hipLaunchKernelGGL((pw_proj_kernel<false, T, NTC>), grid, dim3(256), lds, st, b);
     FR_LAUNCH_CHECK("pw_proj_kernel");
     return FR_OK;
+}
+
+// n-tiles per block: all of them when there are at most 5, else the count in 5, 4, 3 that wastes the fewest tiles
+static int pw_proj_ntc(int NT) {
+    if (NT <= PJ_NT) return std::max(NT, 2);
+    int best = 5;
+    for (int n = 4; n >= 3; --n)
+        if (cdiv(NT, n) * n < cdiv(NT, best) * best) best = n;
+    return best;
+}
+
+template <typename T>
+static int launch_pw_proj(const PwArgs& a, hipStream_t st) {
+    switch (pw_proj_ntc(a.NT)) {
+        case 2: return launch_pw_proj_n<T, 2>(a, st);
+        case 3: return launch_pw_proj_n<T, 3>(a, st);
+        case 4: return launch_pw_proj_n<T, 4>(a, st);
+        default: return launch_pw_proj_n<T, 5>(a, st);
+    }
 }
 
 // ---- streaming variant: all weights (+bias/slope) resident in LDS, K <= 128, bf16 input.
@@ -739,7 +770,8 @@ __global__ __launch_bounds__(256) void fc_splitk_reduce_kernel(const float* __re
 
 // K slices of the split-K Linear for a reduction length of K (0: use fc_kernel).  A function of K only.
 int fc_splitk_slices(int K) {
-    static const int env = [] { const char* s = getenv("FR_FC_SPLITK"); return s ? atoi(s) : -1; }();   // tuning: 0 = off
+    const char* es = getenv("FR_FC_SPLITK");              // tuning, read when a plan is created: 0 = off
+    const int env = es ? atoi(es) : -1;
     if (env == 0 || K < 8192) return 0;
     return env > 0 ? std::min(env, 32) : 8;
 }

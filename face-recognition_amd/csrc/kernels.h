@@ -91,6 +91,7 @@ struct ConvArgs {
     int H, W, Ho, Wo, Cin, ksize, stride, pad;
     int bk;               // channels per K slice the weights were packed with (32; 64 for the bf16 LDS-DMA path)
     const void* zeros;    // >= 64 B of device zeros (source of padded taps in the LDS-DMA path), or NULL
+    int spb;              // conv_halo16_kernel: K slices per barrier (1..3; 0 = default 2), from FR_CONV_SPB when the plan was created
     int halo;             // 1: take conv_halo_kernel where conv_halo_rows() allows it (the plan packed with bk 32 for that); 2: conv_halo16_kernel (weights in its row order)
 };
 int launch_conv(bool in_f32, bool out_f32, const ConvArgs& a, hipStream_t st);

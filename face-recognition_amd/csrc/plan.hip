@@ -44,6 +44,7 @@ struct Layer {
     int slot = -1;                        // output slot
     int slot_pool = -1, slot_hidden = -1; // SE extras (fp32 [N,C], [N,S]); slot = scale [N,C]
     int slot_partial = -1, pool_tiles = 0; // depthwise feeding an SE block: per-tile channel sums [N,pool_tiles,C] fp32
+    int conv_spb = 0;                     // conv_halo16_kernel: K slices per barrier (0 = default)
     int splitk = 0;                       // long-K Linear: K slices of fc_splitk_kernel (partial sums in slot_partial); 0 = fc_kernel
     // device parameters
     bf16* w_packed = nullptr;             // GEMM-shaped kernels
@@ -269,6 +270,7 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
             if (L.conv_halo) L.conv_bk = 32;                  // the shared-pixel kernel walks 32-channel chunks
             // FR_CONV_MFMA=32 keeps the shared-pixel kernel on the 32x32x16 MFMA shape (default: 16x16x32)
             L.conv_halo16 = L.conv_halo && !af32 && !(getenv("FR_CONV_MFMA") && atoi(getenv("FR_CONV_MFMA")) == 32);
+            L.conv_spb = getenv("FR_CONV_SPB") ? atoi(getenv("FR_CONV_SPB")) : 0;      // K slices per barrier of conv_halo16_kernel (tuning; 0 = default)
             pack_conv_weights([&](int co, int tap, int c) { return (double)d.weight[((size_t)co * cin + c) * 9 + tap] * scale[co]; },
                               d.cout, L.H * L.W, d.cin, 9, L.in_f32 ? 2 : 1, L.conv_bk, packed, L.conv_halo16);
             int rc = upload(pl, packed, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
@@ -591,6 +593,7 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
                 a.e = EpiArgs{L.bias, L.slope, res, y, L.cout, L.act};
                 a.M = (long)N * L.H * L.W; a.H = L.inH; a.W = L.inW; a.Ho = L.H; a.Wo = L.W;
                 a.Cin = L.cin; a.ksize = 3; a.stride = L.stride; a.pad = L.pad; a.zeros = plan->zeros; a.bk = L.conv_bk; a.halo = L.conv_halo16 ? 2 : (L.conv_halo ? 1 : 0);
+                a.spb = L.conv_spb;
                 rc = launch_conv(L.in_f32, L.out_f32, a, st);
                 break;
             }

@@ -334,6 +334,60 @@ def test_shared_pixel_conv_equals_per_tap_conv(name, batch, golden_x, monkeypatc
     assert torch.equal(a, a[:8].repeat((batch + 7) // 8, 1)[:batch])
 
 
+@pytest.mark.parametrize("name,batch", [("sphere20", 131), ("sphere36", 9)])
+def test_conv_slices_per_barrier_are_bit_identical(name, batch, golden_x, monkeypatch):
+    """conv_halo16_kernel with 1, 2 (default) and 3 K slices per barrier (FR_CONV_SPB, read when a plan is created): the
+    weight ring only changes how many slices one DMA + barrier covers, not the accumulation order, so the embeddings are
+    bit-identical -- on 131 images (256-pixel blocks, both sub-batches, ragged tiles) and on 9 (128-pixel blocks).  With
+    2 slices per barrier a stage straddles the 9-tap chunk boundary on every other chunk: the frame-staging schedule
+    (next frame only while all slices of an iteration read the current one) is what this pins."""
+    x8 = golden_x.to(DEV)
+    x = x8.repeat((batch + 7) // 8, 1, 1, 1)[:batch].contiguous()
+    m = product(name)
+    outs = {}
+    try:
+        for spb in ("1", "2", "3"):
+            monkeypatch.setenv("FR_CONV_SPB", spb)
+            m.invalidate()
+            with torch.no_grad():
+                outs[spb] = m(x, precision="bf16").clone()
+            assert "conv_halo16_kernel" in [r[1] for r in m.plan(DEV, "bf16", True).profile(x8)]
+    finally:
+        monkeypatch.delenv("FR_CONV_SPB")
+        m.invalidate()
+    assert torch.equal(outs["1"], outs["2"]) and torch.equal(outs["1"], outs["3"])
+    assert torch.equal(outs["2"], outs["2"][:8].repeat((batch + 7) // 8, 1)[:batch])
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f32"])
+def test_split_k_linear_against_whole_k_and_batch_invariance(precision, golden_x, monkeypatch):
+    """The SphereFace fc (25088 -> 512) on fc_splitk_kernel (8 K slices + ordered reduce, the default for K >= 8192)
+    against fc_kernel (FR_FC_SPLITK=0, read when a plan is created): same products, another summation order, so equal
+    to fp32 round-off (|d| <= 2e-5 of the embedding norm), and the embedding cosine 1 to 1e-6.  The slice count
+    depends on K only: an image's embedding is bit-identical at batch 1, 8, 70 and 300 (one and two sub-batches)."""
+    x8 = golden_x.to(DEV)
+    m = product("sphere20")
+    with torch.no_grad():
+        a = m(x8, precision=precision).clone()
+        names = [r[1] for r in m.plan(DEV, precision, True).profile(x8)]
+        assert names[-1] == "fc_splitk_kernel(+reduce)", names[-1]
+        for batch in (1, 70, 300):
+            xb = x8.repeat((batch + 7) // 8, 1, 1, 1)[:batch].contiguous()
+            assert torch.equal(m(xb, precision=precision), a.repeat((batch + 7) // 8, 1)[:batch]), batch
+    monkeypatch.setenv("FR_FC_SPLITK", "0")
+    m.invalidate()
+    try:
+        with torch.no_grad():
+            b = m(x8, precision=precision).clone()
+        assert [r[1] for r in m.plan(DEV, precision, True).profile(x8)][-1] == "fc_kernel"
+    finally:
+        monkeypatch.delenv("FR_FC_SPLITK")
+        m.invalidate()
+    assert float((a - b).norm(dim=1).max() / b.norm(dim=1).min()) <= 2e-5
+    cos = torch.nn.functional.cosine_similarity(a.double(), b.double())
+    assert float(cos.min()) >= 1 - 1e-6
+
+
 class _OddConvNet(fr.models.HipBackbone):
     """Not a reference model: dense 3x3 convs with channel counts the SphereFace nets never use (cout tiles that are
     partly empty, cin not a multiple of 64), stride-1 layers with and without residual on 56x56 and 28x28 maps."""
