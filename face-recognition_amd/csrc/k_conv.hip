@@ -789,23 +789,26 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void conv_halo16_kernel(ConvArgs a
 // rows of the staged pixel range (multiple of 16), or 0 when the shape does not take the shared-pixel kernel
 int conv_halo_rows(int ksize, int stride, int pad, int W, int bk) {
     if (ksize != 3 || stride != 1 || pad != 1 || bk != 32) return 0;
-    static const int min_w = [] { const char* e = getenv("FR_CONV_HALO_MINW"); return e ? atoi(e) : 12; }();   // tuning
-    if (W < min_w) return 0;   // 7x7 maps (512 channels, few pixel tiles): the per-tap kernel with 64-channel slices measured faster
+    static const int min_w = [] { const char* e = getenv("FR_CONV_HALO_MINW"); return e ? atoi(e) : 7; }();   // tuning (12: the 7x7 maps stay on the per-tap kernel, round 2's choice)
+    if (W < min_w) return 0;
     const int rb = (128 + 2 * W + 2 + 15) / 16 * 16;
     return rb <= 576 ? rb : 0;                       // 9 taps x 4 waves x 16 rows: a ninth of the range per tap
 }
 
-// couts per block tile.  Small maps (the 7x7 stage of SphereFace: 49 output pixels per image) take 64-cout tiles:
-// their layers have so few pixel tiles that 128-cout blocks leave the chip at 1-2 waves per SIMD.
-int conv_block_couts(int cout, int out_hw) {
-    static const int small_hw = [] { const char* s = getenv("FR_CONV_BN64_HW"); return s ? atoi(s) : 0; }();   // tuning
-    return cout >= 128 && out_hw > small_hw ? 128 : 64;
+// couts per block tile (the packing granularity).  Layers that run the shared-pixel kernel on maps below 12 x 12 (the 7x7
+// stage of SphereFace: 49 pixels per image, 98 pixel tiles of 128 for a 256-image sub-batch) take 64-cout tiles: twice the
+// blocks for a stage whose 128-cout blocks leave the chip at 1-2 waves per SIMD (sphere64 stage 4: 0.464 -> 0.448 ms per
+// 256 images; with 128-cout tiles the shared-pixel kernel is SLOWER than the per-tap kernel there, 0.477).  The per-tap
+// kernel keeps 128 (64: 0.665 ms).  FR_CONV_BN64_HW (tuning): map size below which that applies (default 144, 0 = never).
+int conv_block_couts(int cout, int out_hw, bool halo) {
+    static const int small_hw = [] { const char* s = getenv("FR_CONV_BN64_HW"); return s ? atoi(s) : 144; }();
+    return cout >= 128 && !(halo && out_hw < small_hw) ? 128 : 64;
 }
 
 template <typename TIn, typename TOut>
 static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
     constexpr int NS = std::is_same<TIn, float>::value ? 2 : 1;
-    const int bn = conv_block_couts(a.e.cout, a.Ho * a.Wo);
+    const int bn = conv_block_couts(a.e.cout, a.Ho * a.Wo, a.halo != 0);
     dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)cdiv(a.e.cout, bn));
     if constexpr (std::is_same<TIn, bf16>::value) {
         if (a.zeros) {

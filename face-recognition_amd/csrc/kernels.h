@@ -95,7 +95,7 @@ struct ConvArgs {
     int halo;             // 1: take conv_halo_kernel where conv_halo_rows() allows it (the plan packed with bk 32 for that); 2: conv_halo16_kernel (weights in its row order)
 };
 int launch_conv(bool in_f32, bool out_f32, const ConvArgs& a, hipStream_t st);
-int conv_block_couts(int cout, int out_hw);   // couts per block tile (64 or 128) of a layer with out_hw output pixels per image: the packing granularity
+int conv_block_couts(int cout, int out_hw, bool halo);   // couts per block tile (64 or 128) of a layer with out_hw output pixels per image (halo: it runs the shared-pixel kernel): the packing granularity
 int conv_halo_rows(int ksize, int stride, int pad, int W, int bk);   // > 0: shape the 3x3 stride-1 shared-pixel kernel takes (bk 32); rows of its staged range at 128 pixels
 
 // ---- weighted spatial reduction: out[n][c] = sum_p x[n][p][c] * w[p][c] (+ b[c]); w NULL -> 1/P

@@ -150,8 +150,8 @@ void pack_gemm_weights(const std::vector<double>& W, int cout, int K, int ns, st
 // row16: the row order of conv_halo16_kernel (16x16x32 MFMA): row rr of a wave's 64 couts holds cout
 // 16 * ((rr % 16) / 4) + 4 * (rr / 16) + rr % 4, so that lane group kg collects couts 16 kg .. 16 kg + 15.
 template <typename F>
-void pack_conv_weights(F&& wfn, int cout, int out_hw, int cin, int taps, int ns, int bk, std::vector<uint16_t>& out, bool row16 = false) {
-    const int bn = conv_block_couts(cout, out_hw), ntiles = cdiv(cout, bn), chunks = cin / bk, KS = taps * chunks;
+void pack_conv_weights(F&& wfn, int cout, int out_hw, bool halo, int cin, int taps, int ns, int bk, std::vector<uint16_t>& out, bool row16 = false) {
+    const int bn = conv_block_couts(cout, out_hw, halo), ntiles = cdiv(cout, bn), chunks = cin / bk, KS = taps * chunks;
     out.assign((size_t)ntiles * KS * ns * bn * bk, 0);
     for (int nt = 0; nt < ntiles; ++nt)
         for (int ks = 0; ks < KS; ++ks) {
@@ -272,7 +272,7 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
             L.conv_halo16 = L.conv_halo && !af32 && !(getenv("FR_CONV_MFMA") && atoi(getenv("FR_CONV_MFMA")) == 32);
             L.conv_spb = getenv("FR_CONV_SPB") ? atoi(getenv("FR_CONV_SPB")) : 0;      // K slices per barrier of conv_halo16_kernel (tuning; 0 = default)
             pack_conv_weights([&](int co, int tap, int c) { return (double)d.weight[((size_t)co * cin + c) * 9 + tap] * scale[co]; },
-                              d.cout, L.H * L.W, d.cin, 9, L.in_f32 ? 2 : 1, L.conv_bk, packed, L.conv_halo16);
+                              d.cout, L.H * L.W, L.conv_halo, d.cin, 9, L.in_f32 ? 2 : 1, L.conv_bk, packed, L.conv_halo16);
             int rc = upload(pl, packed, reinterpret_cast<uint16_t**>(&L.w_packed)); if (rc) return rc;
         } else {
             FR_FAIL(FR_ERR_UNSUPPORTED, std::string(where) + "conv shape with no kernel");
@@ -329,7 +329,7 @@ int build_layer(fr_plan* pl, const fr_layer_desc& d, int idx, Layer& L) {
         if (false && K >= 4096 && K % 32 == 0) {  // (the implicit-GEMM route launched 16 blocks for the SphereFace fc; fc_kernel launches 256)
             L.via_conv = true;
             L.conv_bk = (!L.in_f32 && K % 64 == 0) ? 64 : 32;
-            pack_conv_weights([&](int co, int, int c) { return W[(size_t)co * K + c]; }, d.cout, 1, K, 1, L.in_f32 ? 2 : 1, L.conv_bk, packed);
+            pack_conv_weights([&](int co, int, int c) { return W[(size_t)co * K + c]; }, d.cout, 1, false, K, 1, L.in_f32 ? 2 : 1, L.conv_bk, packed);
         } else {
             pack_gemm_weights(W, d.cout, K, L.in_f32 ? 2 : 1, packed, &L.KS, &L.NT);
             int ntb; pw_pick_tiling(L.in_f32, L.NT, L.KS, &ntb, &L.chunk_ks);
