@@ -465,6 +465,89 @@ def test_dense_conv_odd_shapes_against_torch_fp32(batch, monkeypatch):
         assert torch.equal(taps["1"][i], taps["0"][i]), i
 
 
+class _OddPointwiseNet(fr.models.HipBackbone):
+    """Not a reference model: 1x1 convs with tile counts the MobileNets never produce -- 224 couts behind K = 272 (seven
+    32-cout tiles: column groups of 4 + 3 in pw_proj_kernel), 24 couts behind K = 224 (ONE tile: the kernel's second tile
+    multiplies LDS it never filled), a squeeze-excite block in front of a projection with a residual, a 40-cout tail."""
+
+    def __init__(self):
+        super().__init__()
+        U = fr.models.ConvUnit
+        self.c0 = U(3, 16, 3, 2, act="hswish")                       # 56x56
+        self.e1 = U(16, 272, 1, act="hswish")
+        self.d1 = U(272, 272, 3, 2, groups=272, act="hswish")        # 28x28
+        self.p1 = U(272, 224, 1, act=None)                           # K 272 -> 7 tiles
+        self.d2 = U(224, 224, 5, 1, groups=224)
+        self.se = fr.models.SEUnit(224, 56)
+        self.p2 = U(224, 224, 1, act=None)                           # SE scale + residual p1, 7 tiles
+        self.p3 = U(224, 24, 1, act=None)                            # one tile
+        self.p4 = U(24, 40, 1)
+        self.fc = torch.nn.Linear(40 * 28 * 28, 64)
+        g = torch.Generator().manual_seed(11)
+        for p in self.parameters():
+            with torch.no_grad():
+                p.copy_(torch.randn(p.shape, generator=g) * (0.08 if p.dim() > 1 else 0.2))
+        for m in self.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                with torch.no_grad():
+                    m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                    m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                    m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+    def lower(self, g):
+        a = self.c0.lower(g, "c0", -1)
+        a = self.e1.lower(g, "e1", a)
+        a = self.d1.lower(g, "d1", a)
+        p1 = self.p1.lower(g, "p1", a)
+        a = self.d2.lower(g, "d2", p1)
+        a = self.se.lower(g, "se", a)
+        p2 = self.p2.lower(g, "p2", a, p1)
+        a = self.p3.lower(g, "p3", p2)
+        a = self.p4.lower(g, "p4", a)
+        g.add("fc", op=fr._lib.FR_OP_LINEAR, src=a, cin=self.fc.in_features, cout=self.fc.out_features,
+              weight=self.fc.weight, bias=self.fc.bias)
+
+    def reference(self, x):
+        """Plain PyTorch fp32 of the same graph: outputs of p1, p2, p3, p4 and the embedding."""
+        F = torch.nn.functional
+        y = self.d1(self.e1(self.c0(x)))
+        p1 = self.p1(y)
+        d2 = self.d2(p1)
+        sc = F.hardsigmoid(self.se.fc2(F.relu(self.se.fc1(d2.mean((2, 3), keepdim=True)))))
+        p2 = self.p2(d2 * sc) + p1
+        p3 = self.p3(p2)
+        p4 = self.p4(p3)
+        return [p1, p2, p3, p4, self.fc(p4.flatten(1))]
+
+
+@pytest.mark.parametrize("precision,bar", [("bf16", 3e-2), ("f32", 2e-5)])
+def test_pointwise_odd_tile_counts_against_torch_fp32(precision, bar):
+    """pw_proj_kernel's compile-time tile counts on shapes outside the MobileNets (see _OddPointwiseNet), 70 images (two
+    128-pixel super-tiles per image row group, a ragged last one): the 1x1 outputs and the embedding against a plain
+    PyTorch fp32 forward on the CPU, relative L2 error per tensor <= 3e-2 in bf16 and <= 2e-5 in f32 (f24 plans have no
+    Linear on a conv output, and share the kernel template); no NaN from the tiles a block multiplies without having filled them."""
+    m = _OddPointwiseNet().eval()
+    torch.manual_seed(3)
+    x = torch.rand(70, 3, 112, 112) * 2 - 1
+    with torch.no_grad():
+        want = m.reference(x)
+    m = m.to(DEV)
+    xg = x.to(DEV)
+    names = m.layer_names()
+    kern = dict((r[0], r[1]) for r in m.plan(DEV, precision, False).profile(xg[:8]))
+    assert kern["p1"] == "pw_proj_kernel", kern                  # K = 272: the large-K kernel in every mode (7 tiles: groups of 4 + 3)
+    if precision != "bf16":                                      # K = 224: large-K kernel in fp32 plans (more than 8 k-steps) only
+        assert kern["p2"] == "pw_proj_kernel" and kern["p3"] == "pw_proj_kernel", kern
+    with torch.no_grad():
+        got = [m.forward_tap(xg, names.index(n), precision=precision)[1].cpu() for n in ("p1", "p2", "p3", "p4")]
+        got.append(m(xg, precision=precision).cpu())
+    m.invalidate()
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.shape == w.shape and bool(torch.isfinite(g).all()), i
+        rel = float((g - w).norm() / w.norm())
+        assert rel <= bar, (i, rel)
+
+
 @pytest.mark.parametrize("name,precision", [("mobilenetv3_small", "bf16"), ("mobilenetv3_small", "f32"), ("mobilenetv1", "bf16"),
                                             ("sphere20", "bf16"), ("sphere20", "f32")])
 def test_uint8_input_equals_transformed_input(name, precision, golden_inputs, golden_x):
