@@ -359,7 +359,25 @@ __global__ __launch_bounds__(256, 2) void pw_proj_kernel(PwArgs a) {
             }
         }
 
-        if constexpr (F32) {
+        if constexpr (F32 && !F24) {
+            // fp32 output through a wave-private staging tile in the (now dead) weight buffers: the direct form wrote 64-byte
+            // pieces per lane at a row stride of cout * 4 bytes and took 18 % of a block's time (cycle-counter stamps)
+            constexpr int PITCH32 = stage_pitch(SG * 32 * 4);
+            unsigned char* stage32 = smem + (size_t)wave * 32 * PITCH32;
+            const long tile0 = m - p, left = a.M - tile0;
+#pragma unroll
+            for (int tg = 0; tg < NTC; tg += SG) {
+                if (tg < nt) {
+#pragma unroll
+                    for (int t = tg; t < tg + SG; ++t)
+                        if (t < NTC && t < nt) epilogue_stage_f32_h(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok, stage32, PITCH32, p, 32 * (t - tg) + 16 * h);
+                    if (left > 0)
+                        stage_flush_f32(stage32, PITCH32, lane, reinterpret_cast<float*>(a.e.y) + tile0 * a.e.cout + (t0 + tg) * 32, a.e.cout,
+                                        min(SG * 32, min(a.e.cout, (t0 + nt) * 32) - (t0 + tg) * 32), left < 32 ? (int)left : 32);
+                }
+            }
+            __syncthreads();                           // the next super-tile's weight DMA writes this region
+        } else if constexpr (F32) {
 #pragma unroll
             for (int t = 0; t < NTC; ++t)
                 if (t < nt) epilogue_store_h<T>(acc[t], a.e, m, 32 * (t0 + t) + 16 * h, m_ok);
@@ -389,6 +407,7 @@ static int launch_pw_proj_n(const PwArgs& a, hipStream_t st) {
     const int groups = cdiv(a.NT, b.ntg);
     dim3 grid((unsigned)std::min<long>(n_super, 4096), (unsigned)groups);
     size_t lds = 2 * (size_t)NTC * (F32 ? 2 * 2 : 4) * 1024 + (F32 ? 0 : 4 * 32 * (size_t)stage_pitch(2 * 64));
+    if (std::is_same<T, float>::value) lds = std::max(lds, 4 * 32 * (size_t)stage_pitch(2 * 32 * 4));   // fp32 output staging lives in the weight buffers
     if (a.se) lds += (size_t)PJ_IMGS * a.K * 4;
     if (a.se) { FR_BIG_LDS((pw_proj_kernel<true, T, NTC>), lds); hipLaunchKernelGGL((pw_proj_kernel<true, T, NTC>), grid, dim3(256), lds, st, b); }
     else hipLaunchKernelGGL((pw_proj_kernel<false, T, NTC>), grid, dim3(256), lds, st, b);
