@@ -34,6 +34,22 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
     const int gy0 = oy0 * S - 1, gx0 = ox0 * S - 1;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
+    // bias and PReLU slopes go to LDS with the patch (waited for with it): read from global memory inside the epilogue they
+    // were two to four dependent memory round trips per 32-pixel sub-tile, seven sub-tiles per wave
+    {
+        const int npb = a.NT * 8;                       // 16-byte units per array (<= 64 couts: 16)
+        if (wave == 3 && lane < 2 * npb) {
+            const int which = lane >= npb, u = lane - which * npb;
+            const float* pb = which ? a.e.slope : a.e.bias;
+            const void* src = pb ? (const void*)(pb + u * 4) : a.zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + a.pb_off), 16, 0, 0);
+        }
+    }
+    EpiArgs e2 = a.e;
+    e2.bias = reinterpret_cast<const float*>(smem + a.pb_off);
+    if (a.e.slope) e2.slope = e2.bias + a.NT * 32;
+
     // fp32 patch by LDS-DMA, 4 bytes per lane (lane after lane = the row-major patch); every copy is
     // issued before the single wait; pixels outside the image read the zero page.  A block owns an
     // 8-row strip of (up to) the whole image width: 100 k tiny blocks of 8x16 pixels were bound by
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
                 // wave-private [32 pixels][32 channels] tile in LDS, written back as contiguous runs of 8 pixels
                 constexpr int PITCH = 64 + 16;
                 unsigned char* stage = smem + a.stage_off + wave * 32 * PITCH;
-                epilogue_stage(acc, a.e, m, 32 * t + 16 * h, true, stage, PITCH, p, 16 * h);
+                epilogue_stage(acc, e2, m, 32 * t + 16 * h, true, stage, PITCH, p, 16 * h);
                 const int ncol = min(32, a.e.cout - 32 * t), cr = ncol >> 3;       // 16-byte chunks per pixel: 1..4
                 __builtin_amdgcn_wave_barrier();
                 for (int c = lane; c < 32 * cr; c += 64) {
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
                 constexpr int PITCH = 64 + 16, PITCH_LO = stage_pitch_lo(32);
                 unsigned char* stage = smem + a.stage_off + wave * 32 * (PITCH + PITCH_LO);
                 unsigned char* stage_lo = stage + 32 * PITCH;
-                epilogue_stage_f24(acc, a.e, m, 32 * t + 16 * h, true, stage, PITCH, stage_lo, PITCH_LO, p, 16 * h);
+                epilogue_stage_f24(acc, e2, m, 32 * t + 16 * h, true, stage, PITCH, stage_lo, PITCH_LO, p, 16 * h);
                 const int ncol = min(32, a.e.cout - 32 * t), cr = ncol >> 3, crl = (ncol + 15) >> 4;
                 const int LP = f24_lo_pitch(a.e.cout);
                 __builtin_amdgcn_wave_barrier();
@@ -187,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
                 }
                 __builtin_amdgcn_wave_barrier();
             } else {
-                epilogue_store<TOut>(acc, a.e, m, 32 * t + 16 * h, ok);
+                epilogue_store<TOut>(acc, e2, m, 32 * t + 16 * h, ok);
             }
         }
     }
@@ -205,6 +221,9 @@ int launch_stem(int out_fmt, const StemArgs& a, hipStream_t st) {
     b.stage_off = (int)lds;
     if (out_fmt == FMT_BF16) lds += 4 * 32 * (64 + 16);
     if (out_fmt == FMT_F24) lds += 4 * 32 * (64 + 16 + stage_pitch_lo(32));
+    if (a.NT > 8) FR_FAIL(FR_ERR_UNSUPPORTED, "stem: more than 256 output channels");
+    b.pb_off = (int)align_up(lds, 16);
+    lds = (size_t)b.pb_off + (size_t)a.NT * 32 * 4 * 2;
     const long blocks = (long)a.N * cdiv(a.Ho, 8) * cdiv(a.Wo, b.TW);
     if (blocks > 0x7FFFFFFFL) FR_FAIL(FR_ERR_ARG, "stem: grid too large");
     const dim3 grid((unsigned)blocks);

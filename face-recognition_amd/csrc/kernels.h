@@ -74,6 +74,7 @@ struct StemArgs {
     int N, H, W, Ho, Wo, stride, NT;
     const void* zeros;    // >= 16 B of device zeros (LDS-DMA source outside the image)
     int stage_off;        // set by the launcher: LDS offset of the output staging tiles
+    int pb_off;           // set by the launcher: LDS offset of the bias, then the PReLU slopes ([NT*32] floats each)
     int TW;               // set by the launcher: output columns per block (8-row strips)
     // uint8 HWC input (fr_embed_u8): x8 != nullptr replaces x; lut = 256 floats ((b/255)-0.5)/0.5
     const unsigned char* x8;
