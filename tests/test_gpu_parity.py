@@ -388,6 +388,43 @@ def test_split_k_linear_against_whole_k_and_batch_invariance(precision, golden_x
     assert float(cos.min()) >= 1 - 1e-6
 
 
+@pytest.mark.parametrize("name", ["mobilenetv3_small", "mobilenetv3_large"])
+def test_squeeze_excite_scales_against_oracle(name, golden_dir, golden_x):
+    """The channel scale of every squeeze-excite block (pooling folded from the depthwise kernel's per-tile sums, fc1 + ReLU,
+    fc2 + hard sigmoid: utils/layers.py:114-118) against the oracle's hardsigmoid(fc2(relu(fc1(mean)))) -- the per-layer
+    test above compares SE blocks only through their consumer.  On the trained-like weights, where the scales are spread
+    over [0, 1] instead of sitting at 0.5.  The deep blocks of this weight set saturate (pre-activations of tens), so the
+    error of their INPUT shows: measured <= 4e-5 on the first blocks, 2.5e-3 on the worst; the bar is 1e-2 absolute and
+    1e-4 on the first three.  An image's scales are bit-identical at batch 8 and 70."""
+    from test_oracle_golden import trained_like_state
+    sd, _ = trained_like_state(name, golden_dir)
+    m = product(name, sd)
+    oracle = ob.build(name)
+    oracle.load_state_dict(sd)
+    oracle.eval()
+    x8 = golden_x.to(DEV)
+    names = m.layer_names()
+    mods = dict(oracle.named_modules())
+    se_layers = [(i, n) for i, n in enumerate(names) if isinstance(mods.get(n), ob.SqueezeExcite)]
+    assert len(se_layers) >= 8
+    want = {}
+    hooks = [mods[n].fc2.register_forward_hook(lambda mod, a, out, n=n: want.__setitem__(n, torch.nn.functional.hardsigmoid(out).flatten(1)))
+             for _, n in se_layers]
+    with torch.no_grad():
+        oracle(golden_x)
+    for hk in hooks:
+        hk.remove()
+    x70 = x8.repeat(9, 1, 1, 1)[:70].contiguous()
+    for k, (i, n) in enumerate(se_layers):
+        _, t = m.forward_tap(x8, i, "f32")
+        got = t.reshape(-1)[:want[n].numel()].reshape(8, -1)          # the tap of an SE block is its scale [N, C] (plan.hip, embed_impl)
+        err = float((got.cpu() - want[n]).abs().max())
+        assert err <= (1e-4 if k < 3 else 1e-2), (n, err)
+        _, t70 = m.forward_tap(x70, i, "f32")
+        assert torch.equal(t70.reshape(-1)[:70 * got.shape[1]].reshape(70, -1), got.repeat(9, 1)[:70]), n
+    assert max(float(w.max() - w.min()) for w in want.values()) > 0.5            # the scales are not all ~0.5
+
+
 class _OddConvNet(fr.models.HipBackbone):
     """Not a reference model: dense 3x3 convs with channel counts the SphereFace nets never use (cout tiles that are
     partly empty, cin not a multiple of 64), stride-1 layers with and without residual on 56x56 and 28x28 maps."""
