@@ -170,7 +170,7 @@ FR_DEV void f24_store8(bf16* hi, unsigned char* lo, const Vec8f& x) {
 FR_DEV float apply_act(float v, int act, float slope) {
     switch (act) {
         case FR_ACT_PRELU:    return v >= 0.f ? v : v * slope;
-        case FR_ACT_HSWISH:   return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+        case FR_ACT_HSWISH:   return v * fminf(fmaxf(fmaf(v, 1.f / 6.f, 0.5f), 0.f), 1.f);       // x * relu6(x + 3) / 6 as fma + med3 + mul (2 packed + 1 VALU per pair less)
         case FR_ACT_RELU:     return fmaxf(v, 0.f);
         case FR_ACT_HSIGMOID: return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
         default:              return v;
@@ -203,7 +203,7 @@ FR_DEV void act8(Vec8f& v, int act, const float* slope8) {
         prelu8(v, *reinterpret_cast<const f32x4*>(slope8), *reinterpret_cast<const f32x4*>(slope8 + 4));
     } else if (act == FR_ACT_HSWISH) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v.v[j] = v.v[j] * fminf(fmaxf(v.v[j] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+        for (int j = 0; j < 8; ++j) v.v[j] = v.v[j] * fminf(fmaxf(fmaf(v.v[j], 1.f / 6.f, 0.5f), 0.f), 1.f);
     } else if (act == FR_ACT_RELU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v.v[j] = relu1(v.v[j]);

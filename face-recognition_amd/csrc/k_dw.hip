@@ -657,7 +657,7 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
                     }
                 } else if constexpr (ACT == FR_ACT_HSWISH) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v.v[j] = v.v[j] * fminf(fmaxf(v.v[j] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                    for (int j = 0; j < 8; ++j) v.v[j] = v.v[j] * fminf(fmaxf(fmaf(v.v[j], 1.f / 6.f, 0.5f), 0.f), 1.f);
                 } else {
                     act8(v, x.act_e, sel ? sel + c : nullptr);
                 }
