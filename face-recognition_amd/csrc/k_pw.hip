@@ -441,7 +441,10 @@ static int launch_pw_proj(const PwArgs& a, hipStream_t st) {
 // KSM: max k-steps.  SG: n-tiles staged together for the coalesced write-back; SG = NTB when the
 // block covers whole output rows (one column group), so that the 32-pixel tile leaves as ONE linear
 // run (a trailing 8- or 16-channel group of its own would again write 16/32-byte pieces).
-template <typename TIn, typename TOut, int NTB, int MT, int KSM = 8 / MT, int SG = (NTB < 2 ? NTB : 2)>
+// ACT: the layer's activation at compile time (FR_ACT_NONE / PRELU / HSWISH / RELU).  With a run-time `act` every 8-channel
+// group of the epilogue carried the whole ladder of uniform branches over all activation forms: the small-K layers are bound by
+// instruction issue (24 -> 72 channels at 56 x 56: ~9 instructions per output element per lane, 61 of its 75 us), not by bytes.
+template <typename TIn, typename TOut, int NTB, int MT, int KSM, int SG, int ACT>
 __global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) {
     // TIn = float (fp32 plans): fp32 activations are split into bf16 hi + lo on load and every product is three
     // MFMA passes against the hi/lo weight fragments, in the order pw_gemm_kernel uses (same bits either way)
@@ -538,7 +541,15 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(PwArgs a, PwGrid pg) 
                                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(bl + cl + 4);
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) { v.v[i] = acc[8 * g + i] + b0[i]; v.v[4 + i] = acc[8 * g + 4 + i] + b1[i]; }
-                                act8(v, a.e.act, bl + NTB * 32 + cl);
+                                if constexpr (ACT == FR_ACT_PRELU) {
+                                    prelu8(v, *reinterpret_cast<const f32x4*>(bl + NTB * 32 + cl), *reinterpret_cast<const f32x4*>(bl + NTB * 32 + cl + 4));
+                                } else if constexpr (ACT == FR_ACT_HSWISH) {
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) v.v[i] = v.v[i] * fminf(fmaxf(fmaf(v.v[i], 1.f / 6.f, 0.5f), 0.f), 1.f);
+                                } else if constexpr (ACT == FR_ACT_RELU) {
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) v.v[i] = relu1(v.v[i]);
+                                }
                                 const long off = m * (long)cout + c;
                                 if (R) {
                                     Vec8f r;
@@ -861,8 +872,14 @@ static int launch_pw_stream_sg(const PwArgs& a, hipStream_t st) {
     size_t lds = (size_t)NTB * a.KS * NS * 1024 + (size_t)NTB * 256;
     lds += 4 * 32 * (size_t)stage_pitch(SG * 32 * kHiBytes<TOut>);
     if (kIsF24<TOut>) lds += 4 * 32 * (size_t)stage_pitch_lo(SG * 32);
-#define FR_PW_GO(MT_, KSM_) do { FR_BIG_LDS((pw_stream_kernel<TIn, TOut, NTB, MT_, KSM_, SG>), lds); \
-        hipLaunchKernelGGL((pw_stream_kernel<TIn, TOut, NTB, MT_, KSM_, SG>), grid, dim3(256), lds, st, a, pg); } while (0)
+#define FR_PW_GO1(MT_, KSM_, ACT_) do { FR_BIG_LDS((pw_stream_kernel<TIn, TOut, NTB, MT_, KSM_, SG, ACT_>), lds); \
+        hipLaunchKernelGGL((pw_stream_kernel<TIn, TOut, NTB, MT_, KSM_, SG, ACT_>), grid, dim3(256), lds, st, a, pg); } while (0)
+#define FR_PW_GO(MT_, KSM_) do { switch (a.e.act) { \
+        case FR_ACT_NONE: FR_PW_GO1(MT_, KSM_, FR_ACT_NONE); break; \
+        case FR_ACT_PRELU: FR_PW_GO1(MT_, KSM_, FR_ACT_PRELU); break; \
+        case FR_ACT_HSWISH: FR_PW_GO1(MT_, KSM_, FR_ACT_HSWISH); break; \
+        case FR_ACT_RELU: FR_PW_GO1(MT_, KSM_, FR_ACT_RELU); break; \
+        default: FR_FAIL(FR_ERR_UNSUPPORTED, "pw: activation with no 1x1 kernel"); } } while (0)
     if constexpr (NS == 2) {
         if (mt == 2) FR_PW_GO(2, 2);
         else if (a.KS <= 4) FR_PW_GO(1, 4);
@@ -874,6 +891,7 @@ static int launch_pw_stream_sg(const PwArgs& a, hipStream_t st) {
         else FR_PW_GO(1, 16);
     }
 #undef FR_PW_GO
+#undef FR_PW_GO1
     FR_LAUNCH_CHECK("pw_stream_kernel");
     return FR_OK;
 }
