@@ -146,7 +146,8 @@ FR_DEV void dw_stage(const DwArgs& a, const DwGeom& g, unsigned char* smem, int 
 // T: format of the LDS tile -- bf16 vectors, fp32 half-planes, or f24 as staged from HBM (hi part [pixel][PP] 16-byte
 // slots, lo part `tile_lo` [pixel][PPL] 16-byte slots of two vectors each).  R24: the activated result is rounded to f24
 // (f24 plans: it is stored as f24, or handed to the fused 1x1 conv as the unfused plan would re-load it).
-template <typename T, int K, int S, bool R24 = false>
+// ACT: the activation at compile time, or -1: a.act at run time (the fused kernels)
+template <typename T, int K, int S, bool R24 = false, int ACT = -1>
 FR_DEV void dw_item(const DwArgs& a, const void* tile, const float* wl, const float* bl, int IW, int PP,
                     unsigned cv, unsigned oy, unsigned sx, Vec8f (&out)[dw_sw<S>()], const unsigned char* tile_lo = nullptr, int PPL = 0) {
     constexpr int SW = dw_sw<S>();
@@ -205,7 +206,7 @@ FR_DEV void dw_item(const DwArgs& a, const void* tile, const float* wl, const fl
         wrow += K * 2 * CBV * 4;
     }
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-    if (a.act == FR_ACT_PRELU) {
+    if (ACT == FR_ACT_PRELU || (ACT < 0 && a.act == FR_ACT_PRELU)) {
         s0 = *reinterpret_cast<const f32x4*>(bl + CBV * 8 + (0 * CBV + cv) * 4);
         s1 = *reinterpret_cast<const f32x4*>(bl + CBV * 8 + (1 * CBV + cv) * 4);
     }
@@ -213,7 +214,9 @@ FR_DEV void dw_item(const DwArgs& a, const void* tile, const float* wl, const fl
     for (int o = 0; o < SW; ++o) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[o].v[j] = acc[o][j];
-        if (a.act == FR_ACT_PRELU) prelu8(out[o], s0, s1);
+        if constexpr (ACT == FR_ACT_PRELU) prelu8(out[o], s0, s1);
+        else if constexpr (ACT >= 0) act8(out[o], ACT, nullptr);           // (a constant: the other forms fold away)
+        else if (a.act == FR_ACT_PRELU) prelu8(out[o], s0, s1);
         else act8(out[o], a.act, nullptr);
         if constexpr (R24) {
 #pragma unroll
@@ -222,7 +225,7 @@ FR_DEV void dw_item(const DwArgs& a, const void* tile, const float* wl, const fl
     }
 }
 
-template <typename T, int K, int S>
+template <typename T, int K, int S, int ACT>
 __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SW = dw_sw<S>();                  // outputs per work item (see dw_pick_tile)
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, DwGeom g) {
         else { oy = div32(r, g.d_ns); sx = r - oy * g.nstrips; }
         if ((int)cv >= ncv) return;
         Vec8f out[SW];
-        dw_item<T, K, S, kIsF24<T>>(a, tile, wl, bl, IW, g.PP, cv, oy, sx, out, tile_lo, g.PPL);
+        dw_item<T, K, S, kIsF24<T>, ACT>(a, tile, wl, bl, IW, g.PP, cv, oy, sx, out, tile_lo, g.PPL);
         const int gy = oy0 + (int)oy;
         if (gy < a.Ho) {
             const int gx0o = ox0 + (int)sx * SW;
@@ -379,7 +382,13 @@ static int launch_dw_t(int k, int s, const DwArgs& a, DwGeom g, size_t lds, hipS
         g.n0 = n0;
         dim3 grid((unsigned)(a.tiles_x * a.cchunks), (unsigned)a.tiles_y, (unsigned)std::min(65535, a.N - n0));
         dw_block_geom(g, (int)grid.x, (int)grid.y, (int)grid.z);
-#define FR_DW_CASE(KK, SS) if (k == KK && s == SS) { hipLaunchKernelGGL((dw_kernel<T, KK, SS>), grid, dim3(256), lds, st, a, g); }
+        // the activation is a template parameter: per output the run-time form walks a ladder of uniform branches
+#define FR_DW_CASE(KK, SS) if (k == KK && s == SS) { switch (a.act) { \
+            case FR_ACT_NONE: hipLaunchKernelGGL((dw_kernel<T, KK, SS, FR_ACT_NONE>), grid, dim3(256), lds, st, a, g); break; \
+            case FR_ACT_PRELU: hipLaunchKernelGGL((dw_kernel<T, KK, SS, FR_ACT_PRELU>), grid, dim3(256), lds, st, a, g); break; \
+            case FR_ACT_HSWISH: hipLaunchKernelGGL((dw_kernel<T, KK, SS, FR_ACT_HSWISH>), grid, dim3(256), lds, st, a, g); break; \
+            case FR_ACT_RELU: hipLaunchKernelGGL((dw_kernel<T, KK, SS, FR_ACT_RELU>), grid, dim3(256), lds, st, a, g); break; \
+            default: FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: activation with no kernel"); } }
         FR_DW_CASE(3, 1) else FR_DW_CASE(3, 2) else FR_DW_CASE(5, 1) else FR_DW_CASE(5, 2)
         else FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: only k in {3,5}, stride in {1,2}");
 #undef FR_DW_CASE
