@@ -388,7 +388,8 @@ static int launch_dw_t(int k, int s, const DwArgs& a, DwGeom g, size_t lds, hipS
             case FR_ACT_PRELU: hipLaunchKernelGGL((dw_kernel<T, KK, SS, FR_ACT_PRELU>), grid, dim3(256), lds, st, a, g); break; \
             case FR_ACT_HSWISH: hipLaunchKernelGGL((dw_kernel<T, KK, SS, FR_ACT_HSWISH>), grid, dim3(256), lds, st, a, g); break; \
             case FR_ACT_RELU: hipLaunchKernelGGL((dw_kernel<T, KK, SS, FR_ACT_RELU>), grid, dim3(256), lds, st, a, g); break; \
-            default: FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: activation with no kernel"); } }
+            case FR_ACT_HSIGMOID: hipLaunchKernelGGL((dw_kernel<T, KK, SS, FR_ACT_HSIGMOID>), grid, dim3(256), lds, st, a, g); break; \
+            default: FR_FAIL(FR_ERR_ARG, "depthwise: unknown activation"); } }
         FR_DW_CASE(3, 1) else FR_DW_CASE(3, 2) else FR_DW_CASE(5, 1) else FR_DW_CASE(5, 2)
         else FR_FAIL(FR_ERR_UNSUPPORTED, "depthwise: only k in {3,5}, stride in {1,2}");
 #undef FR_DW_CASE

@@ -907,7 +907,8 @@ static int launch_pw_stream(const PwArgs& a, hipStream_t st) {
 template <typename TIn, typename TOut>
 static int launch_pw_t(const PwArgs& a, int ntb, hipStream_t st) {
     if constexpr (std::is_same<TIn, bf16>::value) {
-        if (a.KS <= 16 && a.chunk_ks >= a.KS && (a.KS <= 8 || ntb <= 2)) {
+        // (the streaming kernel is compiled per activation; a hard sigmoid behind a 1x1 conv -- no reference net has one -- takes pw_gemm_kernel)
+        if (a.KS <= 16 && a.chunk_ks >= a.KS && (a.KS <= 8 || ntb <= 2) && a.e.act != FR_ACT_HSIGMOID) {
             switch (ntb) {
                 case 1: return launch_pw_stream<TIn, TOut, 1>(a, st);
                 case 2: return launch_pw_stream<TIn, TOut, 2>(a, st);
@@ -916,7 +917,7 @@ static int launch_pw_t(const PwArgs& a, int ntb, hipStream_t st) {
             }
         }
     } else if constexpr (kWide<TOut>) {
-        if (a.KS <= 8 && a.chunk_ks >= a.KS) {
+        if (a.KS <= 8 && a.chunk_ks >= a.KS && (a.e.act != FR_ACT_HSIGMOID || kIsF24<TIn>)) {
             switch (ntb) {
                 case 1: return launch_pw_stream<TIn, TOut, 1>(a, st);
                 case 2: return launch_pw_stream<TIn, TOut, 2>(a, st);
