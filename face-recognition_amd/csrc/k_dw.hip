@@ -14,6 +14,9 @@
 // kernel therefore gets its divisors as host-computed 32-bit reciprocals, keeps image bases in
 // scalar registers with 32-bit per-lane offsets, and puts (image, tile row) in blockIdx.z/.y.
 #include "dw_core.h"
+#ifndef FR_DWX_U2
+#define FR_DWX_U2 0      // tuning: 1 = two row tiles per iteration in the expand phase (measured: mobilenetv3_large -4 %, mobilenetv2 -0.5 %: registers)
+#endif
 #include <array>
 #include <cstdio>
 #include <cstdlib>
@@ -563,6 +566,11 @@ struct DwpArgs {
     int act_e, Cin, KSe, NTe;
     int off_we, off_in;
     Div32 d_cin8;
+    // STEM form: the layer in front of the depthwise conv is the network's 3x3 stem conv (Cin = 3, stride 1, pad 1) and is
+    // computed here from the fp32 NCHW input: K = 27 (padded to 32, k = c*9 + ky*3 + kx as stem_kernel), KSe = 2
+    const float* xs;      // network input [N,3,H,W] (H, W = the depthwise input size)
+    int off_res;          // > 0: LDS byte offset of the stem output at the tile's own pixels, [TH*TW][C] as stored in HBM
+                          // by the unfused plan: the residual of the 1x1 conv (which then never reads one from HBM)
 };
 
 // Expand phase of the fused block: out[pixel][C] = act(W_e . in[pixel][Cin] + b) for every pixel of the staged
@@ -570,7 +578,7 @@ struct DwpArgs {
 // image.  The kernel is bound by instruction issue (one wave per SIMD and block, three blocks per CU), so
 // everything uniform is decided at compile time: k-steps, channel tiles, the activation (ACT < 0: run-time
 // act8) and whether the tile touches the image border at all (MASK).  Weights and bias live in registers.
-template <typename T, int KSE, int NTE, int ACT, bool MASK>
+template <typename T, int KSE, int NTE, int ACT, bool MASK, bool STEM = false, int U = 1>
 FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, const float* bel, const float* sel,
                        int gy0, int gx0, int wave, int lane) {
     constexpr bool F32 = kWide<T>;                    // fp32-class arithmetic; the expanded tile is fp32 half-planes
@@ -601,54 +609,98 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
             }
         }
     }
-    for (int rt = wave; rt * 32 < npin; rt += 4) {
-        const int pix = rt * 32 + pe;
-        const int pc = pix < npin ? pix : npin - 1;
-        bool inimg = true;
-        if constexpr (MASK) {
-            const unsigned iy = div32(pc, g.d_iw), ix = pc - iy * IW;
-            const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
-            inimg = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        }
-        bf16x8 xf[KSE][NS];
+    // STEM: LDS offsets (in bytes) of the 16 im2col taps this lane feeds, k = 16 sk + 8 he + j = c*9 + ky*3 + kx, inside the
+    // staged fp32 patch [3][IH+2][IW+2] (stem_kernel's order, the natural one of weight.reshape(cout, 27))
+    const int PW = IW + 2;
+    int koff[STEM ? KSE : 1][8];
+    if constexpr (STEM) {
 #pragma unroll
-        for (int sk = 0; sk < KSE; ++sk) {
-            const int kk = 16 * sk + 8 * he;
-            if constexpr (F24) {
-                if (kk < x.Cin) {
-                    const u32x4 hh = *reinterpret_cast<const u32x4*>(inl + pc * rowb + kk * 2);
-                    const unsigned long long ll = *reinterpret_cast<const unsigned long long*>(inl_lo + pc * LPin + kk);
-                    f24_frags(hh, (unsigned)ll, (unsigned)(ll >> 32), xf[sk][0], xf[sk][1]);
-                } else { xf[sk][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xf[sk][1] = xf[sk][0]; }
-            } else if constexpr (F32) {
-                if (kk < x.Cin) split8(load8(reinterpret_cast<const float*>(inl + pc * rowb) + kk), xf[sk][0], xf[sk][1]);
-                else { xf[sk][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xf[sk][1] = xf[sk][0]; }
-            } else {
-                xf[sk][0] = kk < x.Cin ? *reinterpret_cast<const bf16x8*>(inl + pc * rowb + kk * 2) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int sk = 0; sk < KSE; ++sk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * sk + 8 * he + j;
+                const int c = k / 9, r9 = k - 9 * c;
+                const int ky = r9 / 3, kx = r9 - 3 * ky;
+                koff[sk][j] = k < 27 ? ((c * (g.IH + 2) + ky) * PW + kx) * 4 : 0;     // k >= 27 (sk = 1, he = 1, j >= 3): loaded anyway, replaced by 0
+            }
+    }
+    (void)koff; (void)PW;
+    // U row tiles (32 pixels each) per iteration and wave: their fragment loads, MFMA chains and epilogues are independent, so
+    // the scheduler overlaps one tile's LDS and MFMA latencies with the other's instructions (one to two waves per SIMD here)
+    for (int rt0 = wave; rt0 * 32 < npin; rt0 += 4 * U) {
+        int pix[U];
+        bool inimg[U];
+        unsigned iy[U], ix[U];
+        bf16x8 xf[U][KSE][NS];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pix[u] = (rt0 + 4 * u) * 32 + pe;
+            const int pc = pix[u] < npin ? pix[u] : npin - 1;
+            inimg[u] = true; iy[u] = 0; ix[u] = 0;
+            if constexpr (MASK || STEM) { iy[u] = div32(pc, g.d_iw); ix[u] = pc - iy[u] * IW; }
+            if constexpr (MASK) {
+                const int gy = gy0 + (int)iy[u], gx = gx0 + (int)ix[u];
+                inimg[u] = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            }
+#pragma unroll
+            for (int sk = 0; sk < KSE; ++sk) {
+                const int kk = 16 * sk + 8 * he;
+                if constexpr (STEM) {
+                    const unsigned char* patch = inl + (iy[u] * PW + ix[u]) * 4;
+                    // unconditional loads, then a select: `k < 27 ? patch[..] : 0` makes the compiler branch around every single load
+                    // (exec mask, ds_read, lgkmcnt(0) per element: 16 dependent LDS round trips per 32 pixels)
+                    Vec8f v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v.v[j] = *reinterpret_cast<const float*>(patch + koff[sk][j]);
+                    if (sk == 1) {
+#pragma unroll
+                        for (int j = 3; j < 8; ++j) v.v[j] = he ? 0.f : v.v[j];
+                    }
+                    if constexpr (F32) split8(v, xf[u][sk][0], xf[u][sk][1]);
+                    else xf[u][sk][0] = to_frag(v);
+                } else if constexpr (F24) {
+                    if (kk < x.Cin) {
+                        const u32x4 hh = *reinterpret_cast<const u32x4*>(inl + pc * rowb + kk * 2);
+                        const unsigned long long ll = *reinterpret_cast<const unsigned long long*>(inl_lo + pc * LPin + kk);
+                        f24_frags(hh, (unsigned)ll, (unsigned)(ll >> 32), xf[u][sk][0], xf[u][sk][1]);
+                    } else { xf[u][sk][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xf[u][sk][1] = xf[u][sk][0]; }
+                } else if constexpr (F32) {
+                    if (kk < x.Cin) split8(load8(reinterpret_cast<const float*>(inl + pc * rowb) + kk), xf[u][sk][0], xf[u][sk][1]);
+                    else { xf[u][sk][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xf[u][sk][1] = xf[u][sk][0]; }
+                } else {
+                    xf[u][sk][0] = kk < x.Cin ? *reinterpret_cast<const bf16x8*>(inl + pc * rowb + kk * 2) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
             }
         }
-        // 8-channel group cg of this pixel sits at (pix * PP + cg) vectors of sizeof(V8<T>) bytes
-        // (fp32: (pixel * 2 + half) * PP + cg in 16-byte slots, the layout dw_item reads)
-        unsigned char* dst = smem + ((size_t)pix * g.PP * (F32 ? 2 : 1) + 2 * he) * 16;
         // all channel tiles' MFMAs first, then their epilogues: an epilogue right behind its own (single) MFMA waits out
         // the MFMA's latency in s_nops, once per tile, with one wave per SIMD and block to hide it
-        f32x16 accs[NTE];
+        f32x16 accs[U][NTE];
 #pragma unroll
         for (int t = 0; t < NTE; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) accs[t][r] = 0.f;
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[u][t][r] = 0.f;
 #pragma unroll
             for (int sk = 0; sk < KSE; ++sk) {
-                accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][0], xf[sk][0], accs[t], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) accs[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][0], xf[u][sk][0], accs[u][t], 0, 0, 0);
                 if constexpr (F32) {
-                    accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][0], xf[sk][1], accs[t], 0, 0, 0);
-                    accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][1], xf[sk][0], accs[t], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) accs[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][0], xf[u][sk][1], accs[u][t], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) accs[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[t][sk][1], xf[u][sk][0], accs[u][t], 0, 0, 0);
                 }
             }
         }
 #pragma unroll
+        for (int u = 0; u < U; ++u) {
+        // 8-channel group cg of this pixel sits at (pix * PP + cg) vectors of sizeof(V8<T>) bytes
+        // (fp32: (pixel * 2 + half) * PP + cg in 16-byte slots, the layout dw_item reads)
+        unsigned char* dst = smem + ((size_t)pix[u] * g.PP * (F32 ? 2 : 1) + 2 * he) * 16;
+#pragma unroll
         for (int t = 0; t < NTE; ++t) {
-            const f32x16& acc = accs[t];
+            const f32x16& acc = accs[u][t];
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg) {
                 const int c = 32 * t + 16 * he + 8 * gg;
@@ -671,7 +723,26 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
                 } else {
                     act8(v, x.act_e, sel ? sel + c : nullptr);
                 }
-                const bool live = pix < npin && (t < NTE - 1 || c < a.C);
+                const bool live = pix[u] < npin && (t < NTE - 1 || c < a.C);
+                if constexpr (STEM) {
+                    // the tile's own pixels once more, as the unfused plan stores them: the residual of the 1x1 conv
+                    const unsigned oy = iy[u] - (unsigned)a.pad, ox = ix[u] - (unsigned)a.pad;
+                    if (x.off_res && live && oy < (unsigned)a.TH && ox < (unsigned)a.TW) {
+                        unsigned char* rd = smem + x.off_res + ((size_t)(oy * a.TW + ox) * a.C + c) * kHiBytes<T>;
+                        if constexpr (F32) {
+                            f32x4 r0, r1;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { r0[i] = v.v[i]; r1[i] = v.v[4 + i]; }
+                            *reinterpret_cast<f32x4*>(rd) = r0;
+                            *reinterpret_cast<f32x4*>(rd + 16) = r1;
+                        } else {
+                            u32x4 r;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) r[i] = pack2bf(v.v[2 * i], v.v[2 * i + 1]);
+                            *reinterpret_cast<u32x4*>(rd) = r;
+                        }
+                    }
+                }
                 if constexpr (F32) {
                     if constexpr (F24) {                 // what the unfused plan stores and re-loads
 #pragma unroll
@@ -679,7 +750,7 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
                     }
                     f32x4 r0, r1;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { r0[i] = (!MASK || inimg) ? v.v[i] : 0.f; r1[i] = (!MASK || inimg) ? v.v[4 + i] : 0.f; }
+                    for (int i = 0; i < 4; ++i) { r0[i] = (!MASK || inimg[u]) ? v.v[i] : 0.f; r1[i] = (!MASK || inimg[u]) ? v.v[4 + i] : 0.f; }
                     if (live) {
                         *reinterpret_cast<f32x4*>(dst + (4 * t + gg) * 16) = r0;
                         *reinterpret_cast<f32x4*>(dst + (g.PP + 4 * t + gg) * 16) = r1;
@@ -690,18 +761,21 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
                     for (int i = 0; i < 4; ++i) r[i] = pack2bf(v.v[2 * i], v.v[2 * i + 1]);
                     if constexpr (MASK) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) r[i] = inimg ? r[i] : 0u;
+                        for (int i = 0; i < 4; ++i) r[i] = inimg[u] ? r[i] : 0u;
                     }
                     if (live) *reinterpret_cast<u32x4*>(dst + (4 * t + gg) * 16) = r;
                 }
             }
         }
+        }
     }
 }
 
-template <typename T, int K, int S, int KSE, int NTE>
+template <typename T, int K, int S, int KSE, int NTE, bool STEM = false>
 __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     constexpr bool EXPAND = KSE > 0;      // KSE, NTE: k-steps and 32-channel tiles of the expand conv (compile time)
+    // STEM: the conv in front of the depthwise conv is the 3x3 stem conv on the fp32 NCHW network input (KSE = 2: K = 27 -> 32)
+    static_assert(!STEM || (KSE == 2 && !kIsF24<T>), "stem form: two k-steps, bf16 or fp32 plans");
     constexpr bool F32 = kWide<T>;        // fp32-class arithmetic (fp32 or f24 activations): split operands, hi + lo planes
     constexpr bool F24 = kIsF24<T>;
     constexpr int NS = F32 ? 2 : 1;
@@ -747,7 +821,25 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
         const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;
         const unsigned char* Xn = reinterpret_cast<const unsigned char*>(x.xin) + (size_t)n * a.H * a.W * x.Cin * EB;
         const unsigned char* Z = reinterpret_cast<const unsigned char*>(a.zeros);
-        const int nin_hi = npin * cin8 * UPE;           // 16-byte units
+        const int nin_hi = STEM ? 0 : npin * cin8 * UPE;           // 16-byte units
+        if constexpr (STEM) {
+            // fp32 patch [3][IH+2][IW+2] of the network input by LDS-DMA, 4 bytes per lane (lane after lane = the row-major
+            // patch, as stem_kernel stages it); outside the image: the zero page (the stem conv pads with zeros)
+            const int PH = g.IH + 2, PW = IW + 2, total = 3 * PH * PW;
+            const float* Xs = x.xs + (size_t)n * 3 * a.H * a.W;
+            const Div32 d_hw = make_div32_dev(PH * PW), d_w = make_div32_dev(PW);
+            for (int u0 = wave * 64; u0 < total; u0 += 256) {
+                const int u = u0 + lane;
+                if (u < total) {
+                    const unsigned c = div32(u, d_hw), rem = u - c * PH * PW;
+                    const unsigned iy = div32(rem, d_w), ix = rem - iy * PW;
+                    const int gy = gy0 - 1 + (int)iy, gx = gx0 - 1 + (int)ix;
+                    const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                    const float* src = ok ? Xs + ((int)c * a.H + gy) * a.W + gx : reinterpret_cast<const float*>(Z);
+                    __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + x.off_in + u0 * 4), 4, 0, 0);
+                }
+            }
+        }
         for (int u0 = wave * 64; u0 < nin_hi; u0 += 256) {
             const int u = u0 + lane;
             if (u < nin_hi) {
@@ -782,7 +874,7 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
             __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)(reinterpret_cast<const u32x4*>(x.we) + f * 64 + lane),
                                              (dw_lds_ptr_t)(smem + x.off_we + f * 1024), 16, 0, 0);
         // expand bias and slopes: [NTe*32] floats each, behind the staged input
-        const int off_be = x.off_in + ((nin * 16 + 15) & ~15), nbe = NTE * 8;
+        const int off_be = x.off_in + (STEM ? (3 * (g.IH + 2) * (IW + 2) * 4 + 15) & ~15 : (nin * 16 + 15) & ~15), nbe = NTE * 8;
         if (wave == 1 && lane < 2 * nbe) {
             const int which = lane >= nbe, ch = (lane - which * nbe) * 4;
             const float* pb = which ? x.se : x.be;
@@ -793,17 +885,19 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
         const float* sel = x.se ? bel + NTE * 32 : nullptr;
         dw_stage<T, K, S, false>(a, g, smem, n, 0, ty, tx);               // taps + bias; waits for everything
         const bool border = gy0 < 0 || gx0 < 0 || gy0 + g.IH > a.H || gx0 + IW > a.W;
+        // row tiles per iteration of the expand phase (see dwp_expand): two where the accumulators of both fit (<= 2 channel tiles)
+        constexpr int XU = (FR_DWX_U2 && (STEM || NTE <= 2)) ? 2 : 1;     // (off: see FR_DWX_U2)
         if (x.act_e == FR_ACT_RELU) {
-            if (border) dwp_expand<T, KSE, NTE, FR_ACT_RELU, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
-            else dwp_expand<T, KSE, NTE, FR_ACT_RELU, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            if (border) dwp_expand<T, KSE, NTE, FR_ACT_RELU, true, STEM, XU>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            else dwp_expand<T, KSE, NTE, FR_ACT_RELU, false, STEM, XU>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
         } else if (x.act_e == FR_ACT_PRELU && sel) {
-            if (border) dwp_expand<T, KSE, NTE, FR_ACT_PRELU, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
-            else dwp_expand<T, KSE, NTE, FR_ACT_PRELU, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            if (border) dwp_expand<T, KSE, NTE, FR_ACT_PRELU, true, STEM, XU>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            else dwp_expand<T, KSE, NTE, FR_ACT_PRELU, false, STEM, XU>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
         } else if (x.act_e == FR_ACT_HSWISH) {
-            if (border) dwp_expand<T, KSE, NTE, FR_ACT_HSWISH, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
-            else dwp_expand<T, KSE, NTE, FR_ACT_HSWISH, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            if (border) dwp_expand<T, KSE, NTE, FR_ACT_HSWISH, true, STEM, XU>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            else dwp_expand<T, KSE, NTE, FR_ACT_HSWISH, false, STEM, XU>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
         } else {
-            dwp_expand<T, KSE, NTE, -1, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
+            dwp_expand<T, KSE, NTE, -1, true, STEM, XU>(x, g, smem, bel, sel, gy0, gx0, wave, lane);
         }
         __syncthreads();
     }
@@ -851,7 +945,7 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
 
     // 1x1 conv on MFMA: D[cout][pixel] = W . dwo^T, 32 pixels per wave step
     const int p = lane & 31, h = lane >> 5;
-    constexpr int SG = 2;
+    constexpr int SG = STEM ? 1 : 2;     // 32-channel tiles per staged group (stem form: 16..64 couts, and LDS for the patch and the residual)
     constexpr int PITCH = stage_pitch(SG * 32 * EB);
     constexpr int PITCH_LO = stage_pitch_lo(SG * 32);
     unsigned char* stage = smem + x.off_stage + wave * 32 * PITCH;
@@ -863,12 +957,14 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     e2.bias = reinterpret_cast<const float*>(smem + x.off_pb);
     if (x.e.slope) e2.slope = e2.bias + x.NT * 32;
     const int cout = x.e.cout;
+    const bool res_lds = STEM && x.off_res > 0;        // the residual is the stem output kept in LDS, row = pixel of the tile
+    if (res_lds) e2.residual = smem + x.off_res;
     for (int rt = wave; rt * 32 < x.npx_pad; rt += 4) {
         const int px = rt * 32 + p;
         const unsigned oy = div32(px, g.d_tw), ox = px - oy * a.TW;
         const int gy = oy0 + (int)oy, gx = ox0 + (int)ox;
         const bool ok = px < x.npx && gy < a.Ho && gx < a.Wo;
-        const long m = ((long)n * a.Ho + gy) * a.Wo + gx;
+        const long m = res_lds ? (long)px : ((long)n * a.Ho + gy) * a.Wo + gx;
         const unsigned char* xrow = smem + px * x.pitch + 16 * h;
         for (int tg = 0; tg < x.NT; tg += SG) {
 #pragma unroll
@@ -933,7 +1029,7 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     }
 }
 
-struct DwpPlan { int TH, TW; size_t lds; int off_wp, off_stage, npx_pad, pitch, off_we, off_in, off_pb, off_lo; };
+struct DwpPlan { int TH, TW; size_t lds; int off_wp, off_stage, npx_pad, pitch, off_we, off_in, off_pb, off_lo, off_res; };
 
 // Tile for the fused form: all channels in one block, <= 512 work items, everything within 64 KB of LDS
 // (80 KB for fp32 plans: two blocks per CU).  cin > 0: the expand 1x1 conv (cin -> C) is computed in the kernel too.
@@ -963,10 +1059,16 @@ static int dwp_tile_pad() {
 static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int cin, DwpPlan* out) {
     const bool f32 = fmt != FMT_BF16;                     // fp32-class arithmetic: hi + lo planes, fp32 expanded tile
     const bool f24 = fmt == FMT_F24;
+    const bool stem = cin == DWP_STEM || cin == DWP_STEM_RES, stem_res = cin == DWP_STEM_RES;
+    if (stem) {
+        if (f24 || k != 3 || C > 32 || (stem_res && (s != 1 || C != cout))) return false;
+        cin = 3;
+    }
     const int CV = C / 8, sw = s == 2 ? 2 : 4;
     const int ns = f32 ? 2 : 1;
     // output staging per block: 4 waves x 32 pixels x 64 channels (f24: a bf16-shaped tile for the hi halves + a byte tile)
-    const size_t stage_bytes = 4 * 32 * (f24 ? (size_t)stage_pitch(2 * 32 * 2) + stage_pitch_lo(2 * 32) : (size_t)stage_pitch(2 * 32 * (f32 ? 4 : 2)));
+    const size_t stage_bytes = stem ? 4 * 32 * (size_t)stage_pitch(32 * (f32 ? 4 : 2))      // (stem form: one 32-channel tile per staged group)
+                             : 4 * 32 * (f24 ? (size_t)stage_pitch(2 * 32 * 2) + stage_pitch_lo(2 * 32) : (size_t)stage_pitch(2 * 32 * (f32 ? 4 : 2)));
     const size_t in_px_bytes = f24 ? (size_t)cin * 2 + f24_lo_pitch(cin) : (size_t)cin * (f32 ? 4 : 2);   // staged block input per pixel (expand form)
     if (C % 8 || CV > 16 || C > 128 || cout % 8 || cout > 128 || (k != 3 && k != 5) || (s != 1 && s != 2)) return false;
     // fp32 plans without the expand conv: measured per shape on mobilenetv1 / v3 (512-image launches), the fused form wins
@@ -977,12 +1079,12 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
     // bf16 plans, same measurement (mobilenetv1): wins for 16..64 channels (0.066 vs 0.078 ms, 0.067 vs 0.086, 0.039 vs 0.051,
     // 0.054 vs 0.057), loses for 8 (0.146 vs 0.132) and badly for 128 channels on the 14x14 maps (0.076 vs 0.039 per layer)
     if (!f32 && !cin && (C < 16 || C > 64)) return false;
-    if (cin) {        // expand form: 3x3 only, and only the (k-steps, channel tiles) shapes that are instantiated
+    if (cin && !stem) {        // expand form: 3x3 only, and only the (k-steps, channel tiles) shapes that are instantiated
         const int kse = cdiv(cin, 16), nte = cdiv(C, 32);
         if (cin % 8 || k != 3 || !((kse == 1 && (nte == 2 || nte == 3)) || (kse == 2 && nte == 3))) return false;
     }
     const int KS = cdiv(C, 16), NT = cdiv(cout, 32);
-    const int KSe = cdiv(cin, 16), NTe = cdiv(C, 32);
+    const int KSe = stem ? 2 : cdiv(cin, 16), NTe = cdiv(C, 32);
     // row pitch of the LDS depthwise result (one bf16 plane): an odd number of 16-byte slots keeps the b128
     // fragment reads of 8 consecutive rows on distinct bank groups
     const int pitch = C * 2 + ((CV & 1) ? 32 : 16);
@@ -995,6 +1097,9 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
     const int tws[] = {4, 8, 16, 28, 32, 56};
     int fth = 0, ftw = 0;                                 // tuning override: FR_DWP_TILE="C,cin,TH,TW" for the matching layers
     if (const char* ov = getenv("FR_DWP_TILE")) { int c0, ci; if (sscanf(ov, "%d,%d,%d,%d", &c0, &ci, &fth, &ftw) != 4 || c0 != C || ci != cin) fth = ftw = 0; }
+    // stem form (cin = 3 here): 16 x 16 tiles measured best for 16 and 32 channels in both precisions (tools/stem_tile_sweep.sh, 112 x 112
+    // maps, 512 images: mobilenetv3_large bf16 0.323 ms against 0.353..0.51, f32 0.462 against 0.49..0.77; mobilenetv2 0.332 / 0.469)
+    if (!fth && stem && s == 1 && Ho >= 16 && Wo >= 16) { fth = 16; ftw = 16; }     // (stride 2: the cost model; a 33 x 33 input tile does not fit)
     if (!fth && Ho == Wo && !f32)
         for (const DwpTileEntry& e : kDwpTiles)
             if (e.C == C && e.cin == cin && e.Ho == Ho && e.k == k && e.s == s && e.cout == cout) { fth = e.TH; ftw = e.TW; break; }
@@ -1021,7 +1126,11 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
         const size_t off_pb = off_wp + (size_t)NT * KS * ns * 1024;
         const size_t off_we = off_pb + (size_t)NT * 256;
         const size_t off_in = off_we + (size_t)NTe * KSe * ns * 1024;
-        const size_t lds = off_in + (cin ? align_up((size_t)(IH * IW) * in_px_bytes, 16) + (size_t)NTe * 256 : 0);
+        // staged block input (stem form: the fp32 patch [3][IH+2][IW+2]) + the expand conv's bias and slopes; stem form with a
+        // residual: the stem output of the tile's own pixels behind them
+        const size_t in_bytes = stem ? (size_t)3 * (IH + 2) * (IW + 2) * 4 : (size_t)(IH * IW) * in_px_bytes;
+        const size_t off_res = off_in + (cin ? align_up(in_bytes, 16) + (size_t)NTe * 256 : 0);
+        const size_t lds = off_res + (stem_res ? align_up((size_t)th * tw * C * (f32 ? 4 : 2), 16) : 0);
         if (lds > cap) continue;
         const double useful = (double)std::min(th, Ho) * std::min(tw, Wo);
         // staged input per useful output, padded MFMA rows, and a preference for >= 3 blocks per CU
@@ -1029,7 +1138,7 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
         cost *= (double)cdiv(Ho, th) * th * cdiv(Wo, tw) * tw / ((double)Ho * Wo);   // edge waste
         if (cost < best) {
             best = cost; found = true;
-            *out = DwpPlan{th, tw, lds, (int)off_wp, (int)off_stage, npx_pad, pitch, (int)off_we, (int)off_in, (int)off_pb, (int)plane};
+            *out = DwpPlan{th, tw, lds, (int)off_wp, (int)off_stage, npx_pad, pitch, (int)off_we, (int)off_in, (int)off_pb, (int)plane, stem_res ? (int)off_res : 0};
         }
     }
     return found;
@@ -1042,11 +1151,18 @@ bool dwp_supported(int fmt, int k, int stride, int C, int Ho, int Wo, int cout, 
 
 template <typename T>
 static int launch_dwp_t(int k, int stride, const DwpArgs& x, const DwGeom& g, const DwpPlan& pl, bool ex, dim3 grid, hipStream_t st) {
-#define FR_DWP_GO(KK, SS, KE, NE) do { auto kern = dwp_kernel<T, KK, SS, KE, NE>; \
+#define FR_DWP_GO(KK, SS, KE, NE, ...) do { auto kern = dwp_kernel<T, KK, SS, KE, NE, ##__VA_ARGS__>; \
         FR_BIG_LDS_ONCE(kern, pl.lds); \
         hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, st, x, g); } while (0)
 #define FR_DWP_CASE(KK, SS) if (!ex && k == KK && stride == SS) FR_DWP_GO(KK, SS, 0, 0);
 #define FR_DWX_CASE(SS, KE, NE) if (ex && k == 3 && stride == SS && x.KSe == KE && x.NTe == NE) FR_DWP_GO(3, SS, KE, NE);
+    if (x.xs) {                                        // stem form (bf16 / fp32 plans; dwp_pick refuses f24)
+        if constexpr (!kIsF24<T>) {
+            if (ex && k == 3 && stride == 1 && x.NTe == 1) FR_DWP_GO(3, 1, 2, 1, true);
+            else if (ex && k == 3 && stride == 2 && x.NTe == 1) FR_DWP_GO(3, 2, 2, 1, true);
+            else FR_FAIL(FR_ERR_UNSUPPORTED, "stem+dw+1x1: no kernel for this shape");
+        } else FR_FAIL(FR_ERR_UNSUPPORTED, "stem+dw+1x1: not built for f24 plans");
+    } else
     FR_DWP_CASE(3, 1) else FR_DWP_CASE(3, 2) else FR_DWP_CASE(5, 1) else FR_DWP_CASE(5, 2)
     else FR_DWX_CASE(1, 1, 2) else FR_DWX_CASE(2, 1, 2) else FR_DWX_CASE(1, 1, 3) else FR_DWX_CASE(2, 1, 3)
     else FR_DWX_CASE(1, 2, 3) else FR_DWX_CASE(2, 2, 3)
@@ -1061,8 +1177,9 @@ static int launch_dwp_t(int k, int stride, const DwpArgs& x, const DwGeom& g, co
 int launch_dwp(int fmt, int k, int stride, DwArgs a, const bf16* wp, const EpiArgs& e, const DwpExpand* ex, hipStream_t st) {
     DwpPlan pl;
     const bool f32 = fmt != FMT_BF16;
-    const int cin = ex ? ex->Cin : 0;
+    const int cin = !ex ? 0 : ex->stem ? (ex->res_lds ? DWP_STEM_RES : DWP_STEM) : ex->Cin;
     if (!a.zeros || a.N <= 0 || !dwp_pick(fmt, k, stride, a.C, a.Ho, a.Wo, e.cout, cin, &pl)) FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: shape not supported");
+    if (ex && ex->stem && (!ex->xs || a.pad != 1 || (ex->res_lds && e.residual))) FR_FAIL(FR_ERR_ARG, "stem+dw+1x1: inconsistent arguments");
     if (fmt == FMT_F24 && (!e.y_lo || (e.residual && !e.residual_lo) || (ex ? !ex->xin_lo : !a.x_lo)))
         FR_FAIL(FR_ERR_ARG, "dw+1x1: f24 tensors without their lo planes");
     if ((long)a.H * a.W * a.C * 4 >= 0x7FFFFFFFL) FR_FAIL(FR_ERR_UNSUPPORTED, "dw+1x1: image above 2 GB");
@@ -1087,8 +1204,9 @@ int launch_dwp(int fmt, int k, int stride, DwArgs a, const bf16* wp, const EpiAr
     x.off_wp = pl.off_wp; x.off_stage = pl.off_stage; x.off_pb = pl.off_pb;
     if (ex) {
         x.xin = ex->xin; x.xin_lo = ex->xin_lo; x.we = ex->we; x.be = ex->bias; x.se = ex->slope; x.act_e = ex->act; x.Cin = ex->Cin;
-        x.KSe = cdiv(ex->Cin, 16); x.NTe = cdiv(a.C, 32); x.off_we = pl.off_we; x.off_in = pl.off_in;
-        x.d_cin8 = make_div32(ex->Cin / 8);
+        x.KSe = ex->stem ? 2 : cdiv(ex->Cin, 16); x.NTe = cdiv(a.C, 32); x.off_we = pl.off_we; x.off_in = pl.off_in;
+        x.d_cin8 = make_div32(std::max(1, ex->Cin / 8));
+        if (ex->stem) { x.xs = ex->xs; x.Cin = 3; x.off_res = pl.off_res; }
     }
     for (int n0 = 0; n0 < a.N; n0 += 65535) {
         g.n0 = n0;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
             const int k = 16 * s + 8 * h + j;
             const int c = k / 9, r9 = k - 9 * c;
             const int ky = r9 / 3, kx = r9 - 3 * ky;
-            koff[s][j] = k < 27 ? c * IH * IW + ky * IW + kx : -1;
+            koff[s][j] = k < 27 ? c * IH * IW + ky * IW + kx : 0;     // k >= 27 (s = 1, h = 1, j >= 3): loaded anyway, replaced by 0
         }
     const bf16x8* W = reinterpret_cast<const bf16x8*>(a.w);
     const int nsub_x = TW >> 3, nsub = 2 * nsub_x;              // 4x8-pixel sub-tiles of the strip
@@ -138,7 +138,11 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
         for (int s = 0; s < 2; ++s) {
             Vec8f v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v.v[j] = koff[s][j] >= 0 ? patch[koff[s][j] + base] : 0.f;
+            for (int j = 0; j < 8; ++j) v.v[j] = patch[koff[s][j] + base];     // unconditional (a conditional load is a branch + a dependent LDS round trip per element)
+            if (s == 1) {
+#pragma unroll
+                for (int j = 3; j < 8; ++j) v.v[j] = h ? 0.f : v.v[j];
+            }
             if constexpr (SPLIT) split8(v, xh[s], xl[s]);
             else xh[s] = to_frag(v);
         }

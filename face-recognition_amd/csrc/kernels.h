@@ -59,8 +59,15 @@ struct DwpExpand {
     const float* bias;    // padded to a multiple of 32
     const float* slope;   // PReLU slopes or NULL
     int act, Cin;
+    // stem form: the conv in front of the depthwise conv is the network's 3x3 stem (Cin = 3, stride 1, pad 1, weights packed
+    // as for stem_kernel) computed from the fp32 NCHW network input `xs`; xin is unused.  res_lds: the 1x1 conv's residual is
+    // the stem output (kept in LDS; EpiArgs::residual must be NULL)
+    int stem, res_lds;
+    const float* xs;
 };
-bool dwp_supported(int fmt, int k, int stride, int C, int Ho, int Wo, int cout, int cin /* 0: no expand */);
+// cin: 0 = no expand conv; DWP_STEM / DWP_STEM_RES = the stem form (bf16 / fp32 plans, C <= 32), without / with the LDS residual
+enum { DWP_STEM = -1, DWP_STEM_RES = -2 };
+bool dwp_supported(int fmt, int k, int stride, int C, int Ho, int Wo, int cout, int cin);
 int launch_dwp(int fmt, int k, int stride, DwArgs a, const bf16* w_pw_packed, const EpiArgs& pw_epilogue, const DwpExpand* expand, hipStream_t st);
 // Spatial tiles per image launch_dw will use for this layer shape (sizes DwArgs::pool).
 int dw_tiles_per_image(int fmt, int k, int stride, int C, int Ho, int Wo);

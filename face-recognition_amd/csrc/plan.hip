@@ -62,6 +62,10 @@ struct Layer {
     bool fused_next = false;              // (reserved: a layer computed inside the next layer's kernel; none today)
     int fuse_src = -1;                    // 1x1 conv: index of the depthwise layer computed in its kernel (dwp_kernel)
     int fuse_src2 = -1;                   // ... and of the expand 1x1 conv in front of that depthwise layer
+    // stem -> depthwise -> 1x1 in one launch: on the 1x1 conv the index of the stem layer, on the stem layer the index of that
+    // 1x1 conv.  Decided per call: a uint8 input (fr_embed_u8) or a tap on the stem run the stem kernel and the two-layer fusion
+    // instead, so the stem keeps its output slot.
+    int fuse_stem = -1, stem_fused_by = -1;
 };
 
 }  // namespace
@@ -424,6 +428,23 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
                           E.fuse_src < 0 && dwp_supported(af, D.k, D.stride, D.C, D.H, D.W, P.cout, E.K);
         }
         if (!with_expand && !dwp_supported(af, D.k, D.stride, D.C, D.H, D.W, P.cout, 0)) continue;
+        // the 3x3 stem conv in front of the depthwise conv as well (stem -> depthwise -> 1x1 in one launch: the stem output, which
+        // is also the residual of mobilenetv3_large's first block, is never written or read); FR_FUSE_STEM=0 keeps the stem separate
+        const bool fuse_stem = !(getenv("FR_FUSE_STEM") && atoi(getenv("FR_FUSE_STEM")) == 0);
+        if (fuse_stem && !with_expand && D.src == i - 1 && i >= 1) {
+            Layer& S0 = pl->layers[i - 1];
+            const bool res_stem = P.residual == i - 1;
+            // measured per shape (tools/stem_tile_sweep.sh, 512 images, against stem_kernel + dwp_kernel): 32 channels bf16 0.332 vs 0.375 ms,
+            // f32 0.469 vs 0.698; 16 channels f32 0.462 vs 0.490, but bf16 0.323 vs 0.291 -- the stem phase costs a block the same time
+            // whatever the channel count, what it saves grows with the bytes of the stem output: 16-channel bf16 plans keep the two launches
+            const bool pays = af != FMT_BF16 || D.C >= 32;
+            if (pays && S0.kind == K_STEM && S0.stride == 1 && S0.out_fmt == af && S0.residual < 0 && D.pad == 1 && D.inH == S0.H && D.inW == S0.W &&
+                S0.inH == S0.H && S0.inW == S0.W && (P.residual < 0 || res_stem) && last_use[i - 1] <= i + 1 &&
+                dwp_supported(af, D.k, D.stride, D.C, D.H, D.W, P.cout, res_stem ? DWP_STEM_RES : DWP_STEM)) {
+                P.fuse_stem = i - 1;
+                S0.stem_fused_by = i + 1;
+            }
+        }
         D.fused_next = true;
         P.fuse_src = i;
         if (D.src >= 0) last_use[D.src] = std::max(last_use[D.src], i + 1);
@@ -474,6 +495,7 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         if (last_use[i] < 0 && L.slot >= 0) busy[L.slot] = 0;   // dead output (only reachable through taps)
         if (need_input_copy && input_last_use == i) busy[pl->input_slot] = 0;
     }
+    for (const Layer& L : pl->layers) if (L.stem_fused_by >= 0) launches -= 1;
     pl->launches = launches + (pl->layers.back().kind == K_LINEAR ? 0 : 1);
     *out_plan = pl.release();
     return FR_OK;
@@ -561,6 +583,12 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
             if (events) FR_HIP_CHECK(hipEventRecord(events[i + 1], st));
             continue;
         }
+        // stem computed inside the kernel of the following depthwise + 1x1 pair (fp32 NCHW input, no tap on the stem)
+        auto stem_fused_now = [&](int stem_layer) { return stem_layer >= 0 && !x_u8 && tap_layer != stem_layer; };
+        if (L.kind == K_STEM && L.stem_fused_by >= 0 && stem_fused_now(i)) {
+            if (events) FR_HIP_CHECK(hipEventRecord(events[i + 1], st));
+            continue;
+        }
         void* y = (last && L.kind == K_LINEAR) ? (void*)out : (void*)base[L.slot];
         unsigned char* y_lo = lo_of(L);
         const void* xin = nullptr;
@@ -613,8 +641,16 @@ static int embed_impl(const fr_plan* plan, const void* xv, bool x_u8, int batch,
                         ex.xin_lo = E.src < 0 ? in_nhwc_lo : (const unsigned char*)lo_of(plan->layers[E.src]);
                         ex.we = E.w_packed; ex.bias = E.bias; ex.slope = E.slope; ex.act = E.act; ex.Cin = E.K;
                     }
+                    const bool with_stem = stem_fused_now(L.fuse_stem);
+                    if (with_stem) {
+                        const Layer& S0 = plan->layers[L.fuse_stem];
+                        ex.stem = 1; ex.res_lds = L.residual == L.fuse_stem; ex.xs = x;
+                        ex.we = S0.w_packed; ex.bias = S0.bias; ex.slope = S0.slope; ex.act = S0.act; ex.Cin = 3;
+                        a.x = nullptr; a.x_lo = nullptr;
+                        if (ex.res_lds) { res = nullptr; res_lo = nullptr; }
+                    }
                     rc = launch_dwp(afmt, D.k, D.stride, a, L.w_packed, EpiArgs{L.bias, L.slope, res, y, L.cout, L.act, y_lo, res_lo},
-                                    L.fuse_src2 >= 0 ? &ex : nullptr, st);
+                                    (L.fuse_src2 >= 0 || with_stem) ? &ex : nullptr, st);
                     break;
                 }
                 if (L.via_conv) {
@@ -737,7 +773,7 @@ extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char**
     *name = names[L.kind];
     if (L.kind == K_SE && L.src >= 0 && plan->layers[L.src].slot_partial >= 0 && plan->layers[L.src].pool_tiles <= 8)
         *name = "se(2xfc_kernel)";                    // fc1 folds the depthwise kernel's pooling partials itself
-    if (L.fused_next) {
+    if (L.fused_next || L.stem_fused_by >= 0) {
         *name = "(fused into the next layer)";
     } else if (L.kind == K_PW && L.fuse_src >= 0) {
         *name = "dwp_kernel";

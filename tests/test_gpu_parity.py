@@ -288,7 +288,8 @@ def test_fused_expand_depthwise_pointwise_equals_unfused(name, prec, golden_x, m
     names = [r[1] for r in m.plan(DEV, prec, True).profile(x)]
     assert torch.equal(a, b)
     assert torch.equal(big.view(5, len(x), -1), b.unsqueeze(0).expand(5, -1, -1))
-    fused = [i for i in range(2, len(names)) if names[i] == "dwp_kernel" and names[i - 1].startswith("(fused") and names[i - 2].startswith("(fused")]
+    # (layer 0 is the stem conv, which has a fused form of its own: test_fused_stem_depthwise_pointwise_equals_unfused)
+    fused = [i for i in range(3, len(names)) if names[i] == "dwp_kernel" and names[i - 1].startswith("(fused") and names[i - 2].startswith("(fused")]
     assert fused, names
     monkeypatch.setenv("FR_FUSE3", "0")
     m.invalidate()                                   # plans read FR_FUSE3 when they are created
@@ -301,7 +302,97 @@ def test_fused_expand_depthwise_pointwise_equals_unfused(name, prec, golden_x, m
     assert torch.equal(c, b)
     if name != "mobilenetv3_small":                  # (its depthwise layers have 72+ channels: the two-stage form is not taken)
         assert "dwp_kernel" in names2
-    assert not [i for i in range(2, len(names2)) if names2[i] == "dwp_kernel" and names2[i - 2].startswith("(fused")]
+    assert not [i for i in range(3, len(names2)) if names2[i] == "dwp_kernel" and names2[i - 2].startswith("(fused")]
+
+
+class _StemBlockNet(fr.models.HipBackbone):
+    """Not a reference model: a 3x3 stem conv, a depthwise 3x3 conv and a 1x1 conv (the pattern stem -> depthwise -> project that
+    opens mobilenetv2 and mobilenetv3_large), with the channel count, the depthwise stride, the activations and the residual
+    (the stem output added to the 1x1 output, as mobilenetv3_large's first block does) as parameters, then a Linear."""
+
+    def __init__(self, C, cout, stride, stem_act, residual):
+        super().__init__()
+        U = fr.models.ConvUnit
+        self.residual = residual
+        self.c0 = U(3, C, 3, 1, act=stem_act)
+        self.d1 = U(C, C, 3, stride, groups=C, act="prelu")
+        self.p1 = U(C, cout, 1, act=None)
+        self.p2 = U(cout, 8, 1)
+        hw = 112 // stride
+        self.fc = torch.nn.Linear(8 * hw * hw, 32)
+        g = torch.Generator().manual_seed(7 * C + stride)
+        for q in self.parameters():
+            with torch.no_grad():
+                q.copy_(torch.randn(q.shape, generator=g) * (0.15 if q.dim() > 1 else 0.2))
+        with torch.no_grad():
+            self.fc.weight.mul_(0.02)
+        for m in self.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                with torch.no_grad():
+                    m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                    m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                    m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+    def lower(self, g):
+        a0 = self.c0.lower(g, "c0", -1)
+        a1 = self.d1.lower(g, "d1", a0)
+        a2 = self.p1.lower(g, "p1", a1, a0 if self.residual else -1)
+        a3 = self.p2.lower(g, "p2", a2)
+        g.add("fc", op=fr._lib.FR_OP_LINEAR, src=a3, cin=self.fc.in_features, cout=self.fc.out_features,
+              weight=self.fc.weight, bias=self.fc.bias)
+
+    def reference(self, x):
+        y0 = self.c0(x)
+        p1 = self.p1(self.d1(y0))
+        if self.residual:
+            p1 = p1 + y0
+        return p1, self.fc(self.p2(p1).flatten(1))
+
+
+@pytest.mark.parametrize("precision,bar", [("bf16", 2e-2), ("f32", 2e-5)])
+@pytest.mark.parametrize("C,cout,stride,stem_act,residual", [(32, 16, 1, "prelu", False), (16, 16, 1, "hswish", True),
+                                                            (32, 64, 2, "hswish", False), (24, 24, 1, None, True)])
+def test_fused_stem_depthwise_pointwise_equals_unfused(C, cout, stride, stem_act, residual, precision, bar, monkeypatch):
+    """dwp_kernel's stem form (3x3 stem conv on the fp32 NCHW input -> depthwise -> 1x1 in one launch; the stem output, which is
+    also the residual of mobilenetv3_large's first block, stays in LDS): same im2col order, MFMA sequence and rounding points as
+    stem_kernel followed by the depthwise + 1x1 kernel, so bit for bit equal to the plan with FR_FUSE_STEM=0 and to the unfused
+    plan -- 1x1 output and embedding, 5 images and 131 (both halves of the two-stream split), stride 1 (7 x 7 whole tiles) and
+    stride 2 (56 x 56 output: ragged last tile row and column), 16 / 24 / 32 channels, residual from LDS or none -- and close to
+    a plain PyTorch fp32 forward on the CPU (relative L2 <= 2e-2 in bf16, 2e-5 in f32).  A tap on the stem and a uint8 input
+    take the separate stem kernel from the same plan."""
+    m = _StemBlockNet(C, cout, stride, stem_act, residual).eval()
+    torch.manual_seed(C + stride)
+    x = torch.rand(5, 3, 112, 112) * 2 - 1
+    with torch.no_grad():
+        want_p1, want_emb = m.reference(x)
+    m = m.to(DEV)
+    xg = x.to(DEV)
+    names = m.layer_names()
+    ip1 = names.index("p1")
+    got = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("FR_FUSE_STEM", sw)
+        m.invalidate()                                   # plans read FR_FUSE_STEM when they are created
+        kern = [r[1] for r in m.plan(DEV, precision, True).profile(xg)]
+        assert kern[ip1] == "dwp_kernel", kern
+        # (16-channel bf16 plans keep the stem kernel: measured slower fused, plan.hip)
+        assert kern[0].startswith("(fused") == (sw == "1" and not (precision == "bf16" and C < 32)), kern
+        with torch.no_grad():
+            emb, p1 = m.plan(DEV, precision, True).run(xg, tap=ip1)     # (forward_tap takes the unfused plan)
+            big = m(xg.repeat(27, 1, 1, 1)[:131], precision=precision)
+            emb0, c0 = m.plan(DEV, precision, True).run(xg, tap=0)      # tap on the stem: the separate stem kernel, same plan
+            assert torch.equal(emb0, emb)
+        got[sw] = (emb, p1, big, c0)
+    with torch.no_grad():
+        unfused = m(xg, precision=precision, fuse=False)
+    m.invalidate()
+    for a, b in zip(got["1"], got["0"]):
+        assert torch.equal(a, b)
+    assert torch.equal(got["1"][0], unfused)
+    assert torch.equal(got["1"][2], got["1"][0].repeat(27, 1)[:131])
+    for g_, w_ in ((got["1"][1].cpu(), want_p1), (got["1"][0].cpu(), want_emb)):
+        assert g_.shape == w_.shape and bool(torch.isfinite(g_).all())
+        assert float((g_ - w_).norm() / w_.norm()) <= bar
 
 
 @pytest.mark.parametrize("name,batch", [("sphere20", 8), ("sphere36", 131), ("sphere20", 300)])
