@@ -658,17 +658,23 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
                     }
                     if constexpr (F32) split8(v, xf[u][sk][0], xf[u][sk][1]);
                     else xf[u][sk][0] = to_frag(v);
-                } else if constexpr (F24) {
-                    if (kk < x.Cin) {
-                        const u32x4 hh = *reinterpret_cast<const u32x4*>(inl + pc * rowb + kk * 2);
-                        const unsigned long long ll = *reinterpret_cast<const unsigned long long*>(inl_lo + pc * LPin + kk);
-                        f24_frags(hh, (unsigned)ll, (unsigned)(ll >> 32), xf[u][sk][0], xf[u][sk][1]);
-                    } else { xf[u][sk][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xf[u][sk][1] = xf[u][sk][0]; }
-                } else if constexpr (F32) {
-                    if (kk < x.Cin) split8(load8(reinterpret_cast<const float*>(inl + pc * rowb) + kk), xf[u][sk][0], xf[u][sk][1]);
-                    else { xf[u][sk][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xf[u][sk][1] = xf[u][sk][0]; }
                 } else {
-                    xf[u][sk][0] = kk < x.Cin ? *reinterpret_cast<const bf16x8*>(inl + pc * rowb + kk * 2) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    // loaded unconditionally at a clamped channel offset, then zeroed where the half k-step lies beyond Cin: a load
+                    // behind `kk < Cin ? .. : 0` is an exec-masked branch and a dependent LDS round trip of its own per k-step
+                    const int kc = kk < x.Cin ? kk : 0;
+                    const bool dead = kk >= x.Cin;
+                    const bf16x8 z8 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if constexpr (F24) {
+                        const u32x4 hh = *reinterpret_cast<const u32x4*>(inl + pc * rowb + kc * 2);
+                        const unsigned long long ll = *reinterpret_cast<const unsigned long long*>(inl_lo + pc * LPin + kc);
+                        f24_frags(hh, (unsigned)ll, (unsigned)(ll >> 32), xf[u][sk][0], xf[u][sk][1]);
+                    } else if constexpr (F32) {
+                        split8(load8(reinterpret_cast<const float*>(inl + pc * rowb) + kc), xf[u][sk][0], xf[u][sk][1]);
+                    } else {
+                        xf[u][sk][0] = *reinterpret_cast<const bf16x8*>(inl + pc * rowb + kc * 2);
+                    }
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp) xf[u][sk][sp] = dead ? z8 : xf[u][sk][sp];
                 }
             }
         }

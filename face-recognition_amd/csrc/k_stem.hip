@@ -17,7 +17,10 @@
 // code, so the results are bit-identical to feeding the transformed fp32 tensor.
 #include "kernels.h"
 
-template <typename TOut, bool SPLIT, bool U8>
+// ACT: the activation at compile time (FR_ACT_PRELU, FR_ACT_HSWISH), or -1: a.e.act at run time.  With a constant the epilogue's
+// ladder of uniform branches folds away, and the PReLU slopes are read from LDS as LDS (a pointer that is either the caller's
+// array or the staged copy is a generic pointer: flat loads with a full vmcnt + lgkmcnt wait per 8 channels).
+template <typename TOut, bool SPLIT, bool U8, int ACT>
 __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
     constexpr int NS = SPLIT ? 2 : 1;
     constexpr int TH = 8;
@@ -48,7 +51,9 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
     }
     EpiArgs e2 = a.e;
     e2.bias = reinterpret_cast<const float*>(smem + a.pb_off);
-    if (a.e.slope) e2.slope = e2.bias + a.NT * 32;
+    if constexpr (ACT >= 0) e2.act = ACT;
+    if constexpr (ACT == FR_ACT_PRELU) e2.slope = e2.bias + a.NT * 32;
+    else if (a.e.slope) e2.slope = e2.bias + a.NT * 32;
 
     // fp32 patch by LDS-DMA, 4 bytes per lane (lane after lane = the row-major patch); every copy is
     // issued before the single wait; pixels outside the image read the zero page.  A block owns an
@@ -125,20 +130,20 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
             const int k = 16 * s + 8 * h + j;
             const int c = k / 9, r9 = k - 9 * c;
             const int ky = r9 / 3, kx = r9 - 3 * ky;
-            koff[s][j] = k < 27 ? c * IH * IW + ky * IW + kx : 0;     // k >= 27 (s = 1, h = 1, j >= 3): loaded anyway, replaced by 0
+            koff[s][j] = k < 27 ? (c * IH * IW + ky * IW + kx) * 4 : 0;     // bytes; k >= 27 (s = 1, h = 1, j >= 3): loaded anyway, replaced by 0
         }
     const bf16x8* W = reinterpret_cast<const bf16x8*>(a.w);
     const int nsub_x = TW >> 3, nsub = 2 * nsub_x;              // 4x8-pixel sub-tiles of the strip
     for (int st = wave; st < nsub; st += 4) {
         const int sy = st / nsub_x, sx = st - sy * nsub_x;
         const int py = 4 * sy + (p >> 3), px = 8 * sx + (p & 7);
-        const int base = py * S * IW + px * S;
+        const unsigned char* base = smem + (py * S * IW + px * S) * 4;      // (byte offsets: one add per tap)
         bf16x8 xh[2], xl[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             Vec8f v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v.v[j] = patch[koff[s][j] + base];     // unconditional (a conditional load is a branch + a dependent LDS round trip per element)
+            for (int j = 0; j < 8; ++j) v.v[j] = *reinterpret_cast<const float*>(base + koff[s][j]);     // unconditional (a conditional load is a branch + a dependent LDS round trip per element)
             if (s == 1) {
 #pragma unroll
                 for (int j = 3; j < 8; ++j) v.v[j] = h ? 0.f : v.v[j];
@@ -239,12 +244,20 @@ int launch_stem(int out_fmt, const StemArgs& a, hipStream_t st) {
         b.raw_pitch = (3 * IW + 3 + 3) & ~3;
         b.lut_off = (int)align_up((size_t)IH * b.raw_pitch, 16);
         lds = (size_t)b.raw_off + b.lut_off + 1024;
-        if (out_fmt == FMT_F24) hipLaunchKernelGGL((stem_kernel<f24, true, true>), grid, dim3(256), lds, st, b);
-        else if (out_fmt == FMT_F32) hipLaunchKernelGGL((stem_kernel<float, true, true>), grid, dim3(256), lds, st, b);
-        else hipLaunchKernelGGL((stem_kernel<bf16, false, true>), grid, dim3(256), lds, st, b);
-    } else if (out_fmt == FMT_F24) hipLaunchKernelGGL((stem_kernel<f24, true, false>), grid, dim3(256), lds, st, b);
-    else if (out_fmt == FMT_F32) hipLaunchKernelGGL((stem_kernel<float, true, false>), grid, dim3(256), lds, st, b);
-    else hipLaunchKernelGGL((stem_kernel<bf16, false, false>), grid, dim3(256), lds, st, b);
+    }
+    const bool prelu = a.e.act == FR_ACT_PRELU && a.e.slope;
+#define FR_STEM_GO(TO, SP, U8V) do { \
+        if (prelu) hipLaunchKernelGGL((stem_kernel<TO, SP, U8V, FR_ACT_PRELU>), grid, dim3(256), lds, st, b); \
+        else if (a.e.act == FR_ACT_HSWISH) hipLaunchKernelGGL((stem_kernel<TO, SP, U8V, FR_ACT_HSWISH>), grid, dim3(256), lds, st, b); \
+        else hipLaunchKernelGGL((stem_kernel<TO, SP, U8V, -1>), grid, dim3(256), lds, st, b); } while (0)
+    if (a.x8) {
+        if (out_fmt == FMT_F24) FR_STEM_GO(f24, true, true);
+        else if (out_fmt == FMT_F32) FR_STEM_GO(float, true, true);
+        else FR_STEM_GO(bf16, false, true);
+    } else if (out_fmt == FMT_F24) FR_STEM_GO(f24, true, false);
+    else if (out_fmt == FMT_F32) FR_STEM_GO(float, true, false);
+    else FR_STEM_GO(bf16, false, false);
+#undef FR_STEM_GO
     FR_LAUNCH_CHECK("stem_kernel");
     return FR_OK;
 }
