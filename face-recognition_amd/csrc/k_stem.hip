@@ -211,8 +211,28 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemArgs a) {
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-            } else {
+            } else if (a.e.cout < 16) {
+                // (8 channels: 32 contiguous bytes per pixel either way; measured mobilenetv1 x0.25 f32 -2.2 % through the tile)
                 epilogue_store<TOut>(acc, e2, m, 32 * t + 16 * h, ok);
+            } else {
+                // fp32: the same route with a [32 pixels][32 channels] fp32 tile (a lane's 16 channels are 64 B that a direct store
+                // writes as 16-byte pieces cout * 4 bytes away from the neighbour lane's: the isolated-piece pattern of common.h);
+                // mobilenetv3_small f32 +1.7 % (same-box A/B)
+                constexpr int PITCH = stage_pitch(32 * 4);
+                unsigned char* stage = smem + a.stage_off + wave * 32 * PITCH;
+                epilogue_stage_f32(acc, e2, m, 32 * t + 16 * h, true, stage, PITCH, p, 16 * h);
+                const int ncol = min(32, a.e.cout - 32 * t), cr = ncol >> 2;       // 16-byte chunks per pixel: 2..8
+                __builtin_amdgcn_wave_barrier();
+                for (int c = lane; c < 32 * cr; c += 64) {
+                    const int q = c / cr, ch = c - q * cr;
+                    const int y = oy0 + 4 * sy + (q >> 3), xx = ox0 + 8 * sx + (q & 7);
+                    if (y < a.Ho && xx < a.Wo) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + q * PITCH + ch * 16);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(a.e.y) + (((long)n * a.Ho + y) * a.Wo + xx) * a.e.cout + 32 * t + ch * 4) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                (void)ok;
             }
         }
     }
@@ -230,6 +250,7 @@ int launch_stem(int out_fmt, const StemArgs& a, hipStream_t st) {
     b.stage_off = (int)lds;
     if (out_fmt == FMT_BF16) lds += 4 * 32 * (64 + 16);
     if (out_fmt == FMT_F24) lds += 4 * 32 * (64 + 16 + stage_pitch_lo(32));
+    if (out_fmt == FMT_F32 && a.e.cout >= 16) lds += 4 * 32 * stage_pitch(32 * 4);     // (8 channels: direct stores, no tile)
     if (a.NT > 8) FR_FAIL(FR_ERR_UNSUPPORTED, "stem: more than 256 output channels");
     b.pb_off = (int)align_up(lds, 16);
     lds = (size_t)b.pb_off + (size_t)a.NT * 32 * 4 * 2;
