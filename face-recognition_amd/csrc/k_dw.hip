@@ -569,6 +569,7 @@ struct DwpArgs {
     // STEM form: the layer in front of the depthwise conv is the network's 3x3 stem conv (Cin = 3, stride 1, pad 1) and is
     // computed here from the fp32 NCHW input: K = 27 (padded to 32, k = c*9 + ky*3 + kx as stem_kernel), KSe = 2
     const float* xs;      // network input [N,3,H,W] (H, W = the depthwise input size)
+    int off_dwo;          // chunked form (dwc_kernel): LDS byte offset of the depthwise result of one 32-channel chunk
     int off_res;          // > 0: LDS byte offset of the stem output at the tile's own pixels, [TH*TW][C] as stored in HBM
                           // by the unfused plan: the residual of the 1x1 conv (which then never reads one from HBM)
 };
@@ -578,9 +579,11 @@ struct DwpArgs {
 // image.  The kernel is bound by instruction issue (one wave per SIMD and block, three blocks per CU), so
 // everything uniform is decided at compile time: k-steps, channel tiles, the activation (ACT < 0: run-time
 // act8) and whether the tile touches the image border at all (MASK).  Weights and bias live in registers.
+// tbase: first 32-channel tile of the expand conv this call computes (NTE tiles from there; the chunked kernel calls it with
+// NTE = 1 per chunk): weights, bias and slopes are taken from tile tbase + t, the result goes to slots 4 t .. of the pixel.
 template <typename T, int KSE, int NTE, int ACT, bool MASK, bool STEM = false, int U = 1>
 FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, const float* bel, const float* sel,
-                       int gy0, int gx0, int wave, int lane) {
+                       int gy0, int gx0, int wave, int lane, int tbase = 0) {
     constexpr bool F32 = kWide<T>;                    // fp32-class arithmetic; the expanded tile is fp32 half-planes
     constexpr bool F24 = kIsF24<T>;
     constexpr int NS = F32 ? 2 : 1;
@@ -601,11 +604,11 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
 #pragma unroll
             for (int sk = 0; sk < KSE; ++sk)
 #pragma unroll
-                for (int sp = 0; sp < NS; ++sp) wv[t][sk][sp] = wef[((t * KSE + sk) * NS + sp) * 64];
+                for (int sp = 0; sp < NS; ++sp) wv[t][sk][sp] = wef[(((tbase + t) * KSE + sk) * NS + sp) * 64];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                bb[t][q] = *reinterpret_cast<const f32x4*>(bel + 32 * t + 16 * he + 4 * q);
-                if constexpr (ACT == FR_ACT_PRELU) ss[t][q] = *reinterpret_cast<const f32x4*>(sel + 32 * t + 16 * he + 4 * q);
+                bb[t][q] = *reinterpret_cast<const f32x4*>(bel + 32 * (tbase + t) + 16 * he + 4 * q);
+                if constexpr (ACT == FR_ACT_PRELU) ss[t][q] = *reinterpret_cast<const f32x4*>(sel + 32 * (tbase + t) + 16 * he + 4 * q);
             }
         }
     }
@@ -709,7 +712,7 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
             const f32x16& acc = accs[u][t];
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg) {
-                const int c = 32 * t + 16 * he + 8 * gg;
+                const int c = 32 * (tbase + t) + 16 * he + 8 * gg;
                 Vec8f v;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { v.v[i] = acc[8 * gg + i] + bb[t][2 * gg][i]; v.v[4 + i] = acc[8 * gg + 4 + i] + bb[t][2 * gg + 1][i]; }
@@ -729,7 +732,7 @@ FR_DEV void dwp_expand(const DwpArgs& x, const DwGeom& g, unsigned char* smem, c
                 } else {
                     act8(v, x.act_e, sel ? sel + c : nullptr);
                 }
-                const bool live = pix[u] < npin && (t < NTE - 1 || c < a.C);
+                const bool live = pix[u] < npin && ((tbase == 0 && t < NTE - 1) || c < a.C);
                 if constexpr (STEM) {
                     // the tile's own pixels once more, as the unfused plan stores them: the residual of the 1x1 conv
                     const unsigned oy = iy[u] - (unsigned)a.pad, ox = ix[u] - (unsigned)a.pad;
@@ -1035,7 +1038,199 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     }
 }
 
-struct DwpPlan { int TH, TW; size_t lds; int off_wp, off_stage, npx_pad, pitch, off_we, off_in, off_pb, off_lo, off_res; };
+// ---- expand + depthwise + 1x1 with the expanded channels walked in chunks of 32 ------------------------------------------------
+// dwp_kernel's expand form holds the expanded tile of ALL channels in LDS (9 slots of 16 / 32 bytes per input pixel for 64-72
+// channels), which leaves 32..112 output pixels per block: its projection phase keeps one wave of four busy.  Here the block walks
+// the expanded channels in chunks of 32 (one MFMA channel tile): expand chunk -> depthwise chunk -> the chunk's two k-steps of the
+// 1x1 conv into accumulators that stay in registers.  LDS holds 5 slots per input pixel, so a block takes 2-4 x the pixels.
+// The k order of the 1x1 conv (ascending k-steps, hi*hi, hi*lo, lo*hi per step) and every rounding point are those of dwp_kernel
+// and of the separate kernels: bit-identical results.  cout <= 32 (one channel tile), <= 256 output pixels, <= 256 work items per
+// chunk (one depthwise pass), bf16 and fp32 plans.
+template <typename T, int K, int S, int KSE, int NTE>
+__global__ __launch_bounds__(256, 2) void dwc_kernel(DwpArgs x, DwGeom g) {
+    static_assert(!kIsF24<T> && KSE > 0 && NTE >= 2, "chunked form: bf16 / fp32 plans, expand conv with two or more channel tiles");
+    constexpr bool F32 = kWide<T>;
+    constexpr int NS = F32 ? 2 : 1;
+    constexpr int UPE = std::is_same<T, float>::value ? 2 : 1;
+    constexpr int EB = kHiBytes<T>;
+    typedef typename std::conditional<F32, float, T>::type TT;    // format of the depthwise tile in LDS
+    constexpr int SW = dw_sw<S>();
+    constexpr int CVC = 4;                                         // 8-channel vectors per chunk
+    constexpr int PITCHC = CVC * 16 + 16;                          // row pitch of the chunk's depthwise result (5 slots: odd)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DwArgs& a = x.dw;
+    const int CV = a.C >> 3;
+    int tx, ty, n;
+    dw_block(g, a.tiles_x, a.tiles_y, tx, ty, n);
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int IW = g.IW;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+
+    for (int f = wave; f < x.NT * x.KS * NS; f += 4)
+        __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)(reinterpret_cast<const u32x4*>(x.wp) + f * 64 + lane),
+                                         (dw_lds_ptr_t)(smem + x.off_wp + f * 1024), 16, 0, 0);
+    {
+        const int npb = x.NT * 8;
+        if (wave == 2 && lane < 2 * npb) {
+            const int which = lane >= npb, ch = (lane - which * npb) * 4;
+            const float* pb = which ? x.e.slope : x.e.bias;
+            const void* src = (pb && ch < x.e.cout) ? (const void*)(pb + ch) : a.zeros;
+            __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + x.off_pb), 16, 0, 0);
+        }
+    }
+    const void* tile = smem;
+    const float* wl = reinterpret_cast<const float*>(smem + g.tile_bytes);
+    const float* bl = wl + K * K * a.CBV * 8;
+    const int cin8 = x.Cin >> 3, npin = g.IH * IW;
+    const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;
+    {
+        const unsigned char* Xn = reinterpret_cast<const unsigned char*>(x.xin) + (size_t)n * a.H * a.W * x.Cin * EB;
+        const unsigned char* Z = reinterpret_cast<const unsigned char*>(a.zeros);
+        const int nin = npin * cin8 * UPE;              // 16-byte units
+        for (int u0 = wave * 64; u0 < nin; u0 += 256) {
+            const int u = u0 + lane;
+            if (u < nin) {
+                const unsigned q = (unsigned)u / UPE;
+                const unsigned pix = div32(q, x.d_cin8), cv = q - pix * cin8;
+                const unsigned iy = div32(pix, g.d_iw), ix = pix - iy * IW;
+                const int gy = gy0 + (int)iy, gx = gx0 + (int)ix;
+                const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                const unsigned char* src = ok ? Xn + ((gy * a.W + gx) * x.Cin + (int)cv * 8) * EB + (u % UPE) * 16 : Z;
+                __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + x.off_in + u0 * 16), 16, 0, 0);
+            }
+        }
+        for (int f = wave; f < NTE * KSE * NS; f += 4)
+            __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)(reinterpret_cast<const u32x4*>(x.we) + f * 64 + lane),
+                                             (dw_lds_ptr_t)(smem + x.off_we + f * 1024), 16, 0, 0);
+        const int off_be = x.off_in + ((nin * 16 + 15) & ~15), nbe = NTE * 8;
+        if (wave == 1 && lane < 2 * nbe) {
+            const int which = lane >= nbe, ch = (lane - which * nbe) * 4;
+            const float* pb = which ? x.se : x.be;
+            const void* src = (pb && ch < a.C) ? (const void*)(pb + ch) : (const void*)Z;
+            __builtin_amdgcn_global_load_lds((dw_glb_ptr_t)src, (dw_lds_ptr_t)(smem + off_be), 16, 0, 0);
+        }
+    }
+    const int off_be = x.off_in + ((npin * cin8 * UPE * 16 + 15) & ~15);
+    const float* bel = reinterpret_cast<const float*>(smem + off_be);
+    const float* sel = x.se ? bel + NTE * 32 : nullptr;
+    dw_stage<T, K, S, false>(a, g, smem, n, 0, ty, tx);               // taps + bias of ALL channels; waits for everything
+    const bool border = gy0 < 0 || gx0 < 0 || gy0 + g.IH > a.H || gx0 + IW > a.W;
+
+    const int p = lane & 31, h = lane >> 5;
+    f32x16 pacc[2];                                    // this wave's row tiles wave, wave + 4 of the 1x1 conv
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pacc[i][r] = 0.f;
+    const bf16x8* wf = reinterpret_cast<const bf16x8*>(smem + x.off_wp) + lane;
+    const int nitems_c = a.TH * g.nstrips * CVC;       // <= 256 (launcher)
+
+#pragma unroll 1
+    for (int tc = 0; tc < NTE; ++tc) {
+        // (the previous chunk's projection reads of the chunk result are fenced by the barrier behind this expand phase, its
+        // depthwise reads of the tile by the barrier in front of its projection)
+        if (x.act_e == FR_ACT_RELU) {
+            if (border) dwp_expand<T, KSE, 1, FR_ACT_RELU, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane, tc);
+            else dwp_expand<T, KSE, 1, FR_ACT_RELU, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane, tc);
+        } else if (x.act_e == FR_ACT_PRELU && sel) {
+            if (border) dwp_expand<T, KSE, 1, FR_ACT_PRELU, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane, tc);
+            else dwp_expand<T, KSE, 1, FR_ACT_PRELU, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane, tc);
+        } else if (x.act_e == FR_ACT_HSWISH) {
+            if (border) dwp_expand<T, KSE, 1, FR_ACT_HSWISH, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane, tc);
+            else dwp_expand<T, KSE, 1, FR_ACT_HSWISH, false>(x, g, smem, bel, sel, gy0, gx0, wave, lane, tc);
+        } else {
+            dwp_expand<T, KSE, 1, -1, true>(x, g, smem, bel, sel, gy0, gx0, wave, lane, tc);
+        }
+        __syncthreads();
+        // depthwise conv of the chunk's channel vectors (one pass), result as bf16 (hi + lo) into the chunk result
+        {
+            const int ncv = min(CVC, CV - tc * CVC);
+            const int it = threadIdx.x;
+            const unsigned cv = it & (CVC - 1), r = (unsigned)it >> 2;
+            if (it < nitems_c && (int)cv < ncv) {
+                const unsigned oy = div32(r, g.d_ns), sx = r - oy * g.nstrips;
+                Vec8f out[SW];
+                dw_item<TT, K, S, false>(a, tile, wl + tc * CVC * 4, bl + tc * CVC * 4, IW, g.PP, cv, oy, sx, out);
+                unsigned char* d = smem + x.off_dwo + (oy * a.TW + sx * SW) * PITCHC + cv * 16;
+#pragma unroll
+                for (int o = 0; o < SW; ++o) {
+                    if constexpr (F32) {
+                        bf16x8 hi, lo;
+                        split8(out[o], hi, lo);
+                        *reinterpret_cast<u32x4*>(d + o * PITCHC) = __builtin_bit_cast(u32x4, hi);
+                        *reinterpret_cast<u32x4*>(d + x.off_lo + o * PITCHC) = __builtin_bit_cast(u32x4, lo);
+                    } else {
+                        u32x4 v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = pack2bf(out[o].v[2 * i], out[o].v[2 * i + 1]);
+                        *reinterpret_cast<u32x4*>(d + o * PITCHC) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // the chunk's two k-steps of the 1x1 conv
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rt = wave + 4 * i;
+            if (rt * 32 < x.npx_pad) {
+                const unsigned char* xrow = smem + x.off_dwo + (rt * 32 + p) * PITCHC + 16 * h;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int ks = 2 * tc + s;
+                    if (ks < x.KS) {
+                        bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow + 32 * s);
+                        const bool dead = 16 * ks + 8 * h >= a.C;
+                        if (dead) xf = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        pacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks * NS * 64], xf, pacc[i], 0, 0, 0);
+                        if constexpr (F32) {
+                            bf16x8 xl = *reinterpret_cast<const bf16x8*>(xrow + x.off_lo + 32 * s);
+                            if (dead) xl = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                            pacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks * NS * 64], xl, pacc[i], 0, 0, 0);
+                            pacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(ks * NS + 1) * 64], xf, pacc[i], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // epilogue: bias / activation / residual, staged per wave (over the dead tile) and written back as contiguous rows
+    constexpr int PITCH = stage_pitch(32 * EB);
+    unsigned char* stage = smem + x.off_stage + wave * 32 * PITCH;
+    EpiArgs e2 = x.e;
+    e2.bias = reinterpret_cast<const float*>(smem + x.off_pb);
+    if (x.e.slope) e2.slope = e2.bias + x.NT * 32;
+    const int cout = x.e.cout;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rt = wave + 4 * i;
+        if (rt * 32 >= x.npx_pad) continue;
+        const int px = rt * 32 + p;
+        const unsigned oy = div32(px, g.d_tw), ox = px - oy * a.TW;
+        const int gy = oy0 + (int)oy, gx = ox0 + (int)ox;
+        const bool ok = px < x.npx && gy < a.Ho && gx < a.Wo;
+        const long m = ((long)n * a.Ho + gy) * a.Wo + gx;
+        if constexpr (F32) epilogue_stage_f32_h(pacc[i], e2, m, 16 * h, ok, stage, PITCH, p, 16 * h);
+        else epilogue_stage_h(pacc[i], e2, m, 16 * h, ok, stage, PITCH, p, 16 * h);
+        const int cr = (cout * EB) >> 4;
+        const unsigned magic = (65536u + cr - 1) / cr;
+        __builtin_amdgcn_wave_barrier();
+        for (int c = lane; c < 32 * cr; c += 64) {
+            const int q = (int)(((unsigned)c * magic) >> 16), ch = c - q * cr;
+            const int qpx = rt * 32 + q;
+            const unsigned qy = div32(qpx, g.d_tw), qx = qpx - qy * a.TW;
+            const int y = oy0 + (int)qy, xx = ox0 + (int)qx;
+            if (qpx < x.npx && y < a.Ho && xx < a.Wo) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(stage + q * PITCH + ch * 16);
+                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(x.e.y) + ((((long)n * a.Ho + y) * a.Wo + xx) * cout) * (long)EB + ch * 16) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+struct DwpPlan { int TH, TW; size_t lds; int off_wp, off_stage, npx_pad, pitch, off_we, off_in, off_pb, off_lo, off_res, off_dwo; bool chunked; };
 
 // Tile for the fused form: all channels in one block, <= 512 work items, everything within 64 KB of LDS
 // (80 KB for fp32 plans: two blocks per CU).  cin > 0: the expand 1x1 conv (cin -> C) is computed in the kernel too.
@@ -1062,10 +1257,35 @@ static int dwp_tile_pad() {
     return pad;
 }
 
+// Shapes that take the chunked kernel (dwc_kernel) and their tiles: measured against dwp_kernel's best tile, 512 images, expand +
+// depthwise + 1x1 together (tools/chunk_tile_sweep.sh; profiles/tuning/r3_chunk_tiles.txt).  bf16 plans may use 80 KB here (two blocks
+// per CU).  72 channels are chunks of 32 + 32 + 8 -- the third chunk pays a whole expand pass for 8 channels -- and never won.
+struct DwcTileEntry { int f32, C, cin, Ho, k, s, cout, TH, TW; };
+static const DwcTileEntry kDwcTiles[] = {
+    {0, 64, 16, 56, 3, 2, 24, 14, 8},     // mobilenetv3_large features.2, bf16: 0.265 vs 0.295 ms
+    {1, 64, 16, 56, 3, 2, 24, 14, 8},     //                               f32: 0.546 vs 0.559
+    {0, 96, 16, 56, 3, 2, 24, 14, 8},     // mobilenetv2 features.2,       bf16: 0.356 vs 0.416 (f32: 0.887 vs 0.880 at best, not taken)
+    {0, 88, 24, 28, 3, 1, 24, 8, 28},     // mobilenetv3_small features.3, bf16: 0.077 vs 0.102
+    {1, 88, 24, 28, 3, 1, 24, 14, 16},    //                               f32: 0.138 vs 0.161
+    // not taken: mobilenetv3_large features.3 (72 channels) bf16 0.215 vs 0.215, f32 0.438 vs 0.444; mobilenetv3_small features.2
+    // (72 channels, stride 2) bf16 0.119 vs 0.110, f32 0.218 vs 0.202
+};
+
 static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int cin, DwpPlan* out) {
     const bool f32 = fmt != FMT_BF16;                     // fp32-class arithmetic: hi + lo planes, fp32 expanded tile
     const bool f24 = fmt == FMT_F24;
     const bool stem = cin == DWP_STEM || cin == DWP_STEM_RES, stem_res = cin == DWP_STEM_RES;
+    // chunked form (dwc_kernel): expand conv with two or more channel tiles, one cout tile, bf16 / fp32 plans; FR_DWP_CHUNK=0 keeps dwp_kernel
+    // FR_DWP_CHUNK: 1 (default) the measured shapes of kDwcTiles, 2 every eligible shape (tile by the cost model or FR_DWP_TILE:
+    // tools/chunk_tile_sweep.sh), 0 none
+    static const int chunk_mode = getenv("FR_DWP_CHUNK") ? atoi(getenv("FR_DWP_CHUNK")) : 1;
+    bool chunked = chunk_mode > 0 && !stem && cin > 0 && !f24 && k == 3 && C > 32 && cout <= 32;
+    int cth = 0, ctw = 0;
+    if (chunked && chunk_mode == 1) {
+        chunked = false;
+        for (const DwcTileEntry& e : kDwcTiles)
+            if (e.f32 == (int)f32 && e.C == C && e.cin == cin && e.Ho == Ho && Wo == Ho && e.k == k && e.s == s && e.cout == cout) { chunked = true; cth = e.TH; ctw = e.TW; break; }
+    }
     if (stem) {
         if (f24 || k != 3 || C > 32 || (stem_res && (s != 1 || C != cout))) return false;
         cin = 3;
@@ -1073,7 +1293,7 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
     const int CV = C / 8, sw = s == 2 ? 2 : 4;
     const int ns = f32 ? 2 : 1;
     // output staging per block: 4 waves x 32 pixels x 64 channels (f24: a bf16-shaped tile for the hi halves + a byte tile)
-    const size_t stage_bytes = stem ? 4 * 32 * (size_t)stage_pitch(32 * (f32 ? 4 : 2))      // (stem form: one 32-channel tile per staged group)
+    const size_t stage_bytes = (stem || chunked) ? 4 * 32 * (size_t)stage_pitch(32 * (f32 ? 4 : 2))      // (stem / chunked form: one 32-channel tile per staged group)
                              : 4 * 32 * (f24 ? (size_t)stage_pitch(2 * 32 * 2) + stage_pitch_lo(2 * 32) : (size_t)stage_pitch(2 * 32 * (f32 ? 4 : 2)));
     const size_t in_px_bytes = f24 ? (size_t)cin * 2 + f24_lo_pitch(cin) : (size_t)cin * (f32 ? 4 : 2);   // staged block input per pixel (expand form)
     if (C % 8 || CV > 16 || C > 128 || cout % 8 || cout > 128 || (k != 3 && k != 5) || (s != 1 && s != 2)) return false;
@@ -1097,35 +1317,57 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
     static const int cap_env = getenv("FR_DWP_CAP_KB") ? atoi(getenv("FR_DWP_CAP_KB")) : 0;            // tuning: LDS cap of the fused kernels
     // fp32 plans may take ONE block per CU (up to 150 KB): the hi+lo planes leave so few pixels per tile at 80 KB that the expand conv
     // is recomputed 1.9x on the halo (72 channels: 8x4 tiles); a 14x8 tile in 100 KB was 28 % faster (0.44 vs 0.60 ms per 512 images)
-    const size_t cap = cap_env > 0 ? (size_t)cap_env * 1024 : (f32 ? 150 * 1024 : 64 * 1024);
+    const size_t cap = cap_env > 0 ? (size_t)cap_env * 1024 : (f32 ? 150 * 1024 : chunked ? 80 * 1024 : 64 * 1024);
     double best = 1e30; bool found = false;
     const int ths[] = {2, 4, 7, 8, 14, 16};
     const int tws[] = {4, 8, 16, 28, 32, 56};
     int fth = 0, ftw = 0;                                 // tuning override: FR_DWP_TILE="C,cin,TH,TW" for the matching layers
     if (const char* ov = getenv("FR_DWP_TILE")) { int c0, ci; if (sscanf(ov, "%d,%d,%d,%d", &c0, &ci, &fth, &ftw) != 4 || c0 != C || ci != cin) fth = ftw = 0; }
+    if (!fth && cth) { fth = cth; ftw = ctw; }
     // stem form (cin = 3 here): 16 x 16 tiles measured best for 16 and 32 channels in both precisions (tools/stem_tile_sweep.sh, 112 x 112
     // maps, 512 images: mobilenetv3_large bf16 0.323 ms against 0.353..0.51, f32 0.462 against 0.49..0.77; mobilenetv2 0.332 / 0.469)
     if (!fth && stem && s == 1 && Ho >= 16 && Wo >= 16) { fth = 16; ftw = 16; }     // (stride 2: the cost model; a 33 x 33 input tile does not fit)
-    if (!fth && Ho == Wo && !f32)
+    if (!fth && Ho == Wo && !f32 && !chunked)            // (the tables hold dwp_kernel's winners)
         for (const DwpTileEntry& e : kDwpTiles)
             if (e.C == C && e.cin == cin && e.Ho == Ho && e.k == k && e.s == s && e.cout == cout) { fth = e.TH; ftw = e.TW; break; }
-    if (!fth && Ho == Wo && f32)
+    if (!fth && Ho == Wo && f32 && !chunked)
         for (const DwpTileEntry& e : kDwpTilesF32)
             if (e.C == C && e.cin == cin && e.Ho == Ho && e.k == k && e.s == s && e.cout == cout) { fth = e.TH; ftw = e.TW; break; }
     for (int th : ths) for (int tw : tws) {
         if (fth && (th != fth || tw != ftw)) continue;
         if (th == 2 && !f32) continue;                    // (2-row tiles: fp32 plans only, where LDS is the limit)
         if (th - Ho >= 2 || tw - Wo >= 4) continue;
-        const int items = th * (tw / sw) * CV;
-        if (items > 512) continue;
+        const int items = th * (tw / sw) * (chunked ? 4 : CV);
+        if (items > (chunked ? 256 : 512)) continue;      // (chunked: one depthwise pass per chunk, two row tiles per wave)
         const int npx_pad = cdiv(th * tw, 32) * 32;
+        if (chunked && npx_pad > 256) continue;
         const size_t plane = (size_t)npx_pad * pitch, dwo = plane * ns;
         const double IH = (th - 1) * s + k, IW = (tw - 1) * s + k;
         // tile + taps + bias; a tile computed in the kernel has one spare vector slot per pixel, so that the
         // MFMA lanes (one pixel each) write it without bank conflicts
         // (a tile computed in the kernel is fp32 half-planes for both fp32-class formats; one staged from HBM is in the plan's format)
         const int tfmt = cin ? (f32 ? FMT_F32 : FMT_BF16) : fmt;
-        const size_t tile = dw_lds_bytes(tfmt, k, s, th, tw, CV) + (cin ? (size_t)dwp_tile_pad() * (IH * IW) * (f32 ? 32 : 16) : 0);
+        size_t tile = dw_lds_bytes(tfmt, k, s, th, tw, CV) + (cin ? (size_t)dwp_tile_pad() * (IH * IW) * (f32 ? 32 : 16) : 0);
+        if (chunked) {
+            // tile of ONE chunk (4 vectors + the spare slot per pixel), taps and bias of all channels behind it; the chunk's depthwise
+            // result [npx_pad][80 B] (x 2 planes) in a region of its own; the output staging over the tile
+            tile = (size_t)(IH * IW) * (4 + dwp_tile_pad()) * (f32 ? 32 : 16) + (size_t)k * k * CV * 32 + (size_t)CV * 64;
+            const size_t off_dwo = align_up(std::max(tile, stage_bytes), 16);
+            const size_t off_wp = align_up(off_dwo + (size_t)npx_pad * 80 * ns, 1024);
+            const size_t off_pb = off_wp + (size_t)NT * KS * ns * 1024;
+            const size_t off_we = off_pb + (size_t)NT * 256;
+            const size_t off_in = off_we + (size_t)NTe * KSe * ns * 1024;
+            const size_t lds = off_in + align_up((size_t)(IH * IW) * in_px_bytes, 16) + (size_t)NTe * 256;
+            if (lds > cap) continue;
+            const double useful = (double)std::min(th, Ho) * std::min(tw, Wo);
+            double cost = (IH * IW) / useful + 0.5 * npx_pad / useful + (lds > 80 * 1024 ? 1.0 : lds > 53 * 1024 ? 0.4 : lds > 40 * 1024 ? 0.2 : 0.0) + (items < 192 ? 0.5 : 0.0);
+            cost *= (double)cdiv(Ho, th) * th * cdiv(Wo, tw) * tw / ((double)Ho * Wo);
+            if (cost < best) {
+                best = cost; found = true;
+                *out = DwpPlan{th, tw, lds, (int)off_wp, 0, npx_pad, 80, (int)off_we, (int)off_in, (int)off_pb, npx_pad * 80, 0, (int)off_dwo, true};
+            }
+            continue;
+        }
         // the output staging tiles live behind the depthwise result, inside the (by then dead) input tile
         const size_t off_stage = align_up(dwo, 16);
         const size_t off_wp = align_up(std::max(tile, off_stage + stage_bytes), 1024);
@@ -1144,7 +1386,7 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
         cost *= (double)cdiv(Ho, th) * th * cdiv(Wo, tw) * tw / ((double)Ho * Wo);   // edge waste
         if (cost < best) {
             best = cost; found = true;
-            *out = DwpPlan{th, tw, lds, (int)off_wp, (int)off_stage, npx_pad, pitch, (int)off_we, (int)off_in, (int)off_pb, (int)plane, stem_res ? (int)off_res : 0};
+            *out = DwpPlan{th, tw, lds, (int)off_wp, (int)off_stage, npx_pad, pitch, (int)off_we, (int)off_in, (int)off_pb, (int)plane, stem_res ? (int)off_res : 0, 0, false};
         }
     }
     return found;
@@ -1162,6 +1404,16 @@ static int launch_dwp_t(int k, int stride, const DwpArgs& x, const DwGeom& g, co
         hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, st, x, g); } while (0)
 #define FR_DWP_CASE(KK, SS) if (!ex && k == KK && stride == SS) FR_DWP_GO(KK, SS, 0, 0);
 #define FR_DWX_CASE(SS, KE, NE) if (ex && k == 3 && stride == SS && x.KSe == KE && x.NTe == NE) FR_DWP_GO(3, SS, KE, NE);
+    if (pl.chunked) {                                  // chunked form (bf16 / fp32 plans)
+        if constexpr (!kIsF24<T>) {
+#define FR_DWC_CASE(SS, KE, NE) if (ex && k == 3 && stride == SS && x.KSe == KE && x.NTe == NE) { auto kern = dwc_kernel<T, 3, SS, KE, NE>; \
+            FR_BIG_LDS_ONCE(kern, pl.lds); hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, st, x, g); }
+            FR_DWC_CASE(1, 1, 2) else FR_DWC_CASE(2, 1, 2) else FR_DWC_CASE(1, 1, 3) else FR_DWC_CASE(2, 1, 3)
+            else FR_DWC_CASE(1, 2, 3) else FR_DWC_CASE(2, 2, 3)
+            else FR_FAIL(FR_ERR_UNSUPPORTED, "expand+dw+1x1 (chunked): no kernel for this shape");
+#undef FR_DWC_CASE
+        } else FR_FAIL(FR_ERR_UNSUPPORTED, "expand+dw+1x1 (chunked): not built for f24 plans");
+    } else
     if (x.xs) {                                        // stem form (bf16 / fp32 plans; dwp_pick refuses f24)
         if constexpr (!kIsF24<T>) {
             if (ex && k == 3 && stride == 1 && x.NTe == 1) FR_DWP_GO(3, 1, 2, 1, true);
@@ -1199,7 +1451,7 @@ int launch_dwp(int fmt, int k, int stride, DwArgs a, const bf16* wp, const EpiAr
     g.nstrips = a.TW / sw;
     g.nitems = a.TH * g.nstrips * a.CBV;
     g.nunits = g.IH * g.IW * (ex ? a.CBV : a.CBV) * (fmt == FMT_F32 ? 2 : 1);      // (tile staged from HBM only without the expand conv: PP == CBV)
-    g.PP = ex ? a.CBV + dwp_tile_pad() : a.CBV;
+    g.PP = pl.chunked ? 4 + dwp_tile_pad() : ex ? a.CBV + dwp_tile_pad() : a.CBV;
     g.PPL = (a.CBV + 1) / 2;
     g.tile_bytes = (int)dw_tile_bytes(ex ? (f32 ? FMT_F32 : FMT_BF16) : fmt, g.IH, g.IW, g.PP);
     g.d_cbv = make_div32(a.CBV); g.d_iw = make_div32(g.IW); g.d_ns = make_div32(g.nstrips); g.d_tw = make_div32(a.TW);
@@ -1213,6 +1465,7 @@ int launch_dwp(int fmt, int k, int stride, DwArgs a, const bf16* wp, const EpiAr
         x.KSe = ex->stem ? 2 : cdiv(ex->Cin, 16); x.NTe = cdiv(a.C, 32); x.off_we = pl.off_we; x.off_in = pl.off_in;
         x.d_cin8 = make_div32(std::max(1, ex->Cin / 8));
         if (ex->stem) { x.xs = ex->xs; x.Cin = 3; x.off_res = pl.off_res; }
+        x.off_dwo = pl.off_dwo;
     }
     for (int n0 = 0; n0 < a.N; n0 += 65535) {
         g.n0 = n0;
