@@ -159,8 +159,8 @@ def roofline_records(model_name, batch, ms, plan, rows, ms_layer, pb, parts, lay
             # measured HBM rate of the same launches; for a kernel that fuses several layers the algorithmic bytes
             # are those of the unfused layer graph, so `achieved` can exceed it
             r["traffic_GBps"] = round(r["traffic"] / (t_dom / n_dom * 1e-3) / 1e9, 1)
-    if dom == "dwp_kernel":
-        out["roofline"]["note"] = ("dwp_kernel computes 2-3 layers per launch (expand 1x1 + depthwise + project 1x1): "
+    if dom in ("dwp_kernel", "dwc_kernel"):
+        out["roofline"]["note"] = (dom + " computes 2-3 layers per launch (expand 1x1 + depthwise + project 1x1): "
                                    "alg_bytes_per_launch counts every fused layer's input and output as SURVEY.md 8(d) defines "
                                    "them; the intermediate activations never reach HBM, so `frac` is not an HBM utilisation")
     if model_name in ALG_MB_PER_IMG and out["roofline"]["bound"] == "hbm":

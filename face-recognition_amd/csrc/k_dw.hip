@@ -1278,7 +1278,8 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
     // chunked form (dwc_kernel): expand conv with two or more channel tiles, one cout tile, bf16 / fp32 plans; FR_DWP_CHUNK=0 keeps dwp_kernel
     // FR_DWP_CHUNK: 1 (default) the measured shapes of kDwcTiles, 2 every eligible shape (tile by the cost model or FR_DWP_TILE:
     // tools/chunk_tile_sweep.sh), 0 none
-    static const int chunk_mode = getenv("FR_DWP_CHUNK") ? atoi(getenv("FR_DWP_CHUNK")) : 1;
+    const char* chunk_env = getenv("FR_DWP_CHUNK");       // (read per call, like FR_DWP_TILE: tests and sweeps switch it inside one process)
+    const int chunk_mode = chunk_env ? atoi(chunk_env) : 1;
     bool chunked = chunk_mode > 0 && !stem && cin > 0 && !f24 && k == 3 && C > 32 && cout <= 32;
     int cth = 0, ctw = 0;
     if (chunked && chunk_mode == 1) {
@@ -1395,6 +1396,10 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
 bool dwp_supported(int fmt, int k, int stride, int C, int Ho, int Wo, int cout, int cin) {
     DwpPlan pl;
     return dwp_pick(fmt, k, stride, C, Ho, Wo, cout, cin, &pl);
+}
+bool dwp_is_chunked(int fmt, int k, int stride, int C, int Ho, int Wo, int cout, int cin) {
+    DwpPlan pl;
+    return dwp_pick(fmt, k, stride, C, Ho, Wo, cout, cin, &pl) && pl.chunked;
 }
 
 template <typename T>

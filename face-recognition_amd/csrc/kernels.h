@@ -68,6 +68,7 @@ struct DwpExpand {
 // cin: 0 = no expand conv; DWP_STEM / DWP_STEM_RES = the stem form (bf16 / fp32 plans, C <= 32), without / with the LDS residual
 enum { DWP_STEM = -1, DWP_STEM_RES = -2 };
 bool dwp_supported(int fmt, int k, int stride, int C, int Ho, int Wo, int cout, int cin);
+bool dwp_is_chunked(int fmt, int k, int stride, int C, int Ho, int Wo, int cout, int cin);   // the launch will take dwc_kernel (expanded channels in chunks of 32)
 int launch_dwp(int fmt, int k, int stride, DwArgs a, const bf16* w_pw_packed, const EpiArgs& pw_epilogue, const DwpExpand* expand, hipStream_t st);
 // Spatial tiles per image launch_dw will use for this layer shape (sizes DwArgs::pool).
 int dw_tiles_per_image(int fmt, int k, int stride, int C, int Ho, int Wo);

@@ -777,6 +777,10 @@ extern "C" int fr_plan_layer_kernel(const fr_plan* plan, int layer, const char**
         *name = "(fused into the next layer)";
     } else if (L.kind == K_PW && L.fuse_src >= 0) {
         *name = "dwp_kernel";
+        if (L.fuse_src2 >= 0) {
+            const Layer& D = plan->layers[L.fuse_src];
+            if (dwp_is_chunked(plan->act_fmt(), D.k, D.stride, D.C, D.H, D.W, L.cout, plan->layers[L.fuse_src2].K)) *name = "dwc_kernel";
+        }
     } else if (L.kind == K_PW) {
         const bool se = L.src >= 0 && plan->layers[L.src].kind == K_SE;
         *name = pw_kernel_name(L.in_fmt, L.out_fmt, L.K, L.cout, se, L.H * L.W);

@@ -289,7 +289,7 @@ def test_fused_expand_depthwise_pointwise_equals_unfused(name, prec, golden_x, m
     assert torch.equal(a, b)
     assert torch.equal(big.view(5, len(x), -1), b.unsqueeze(0).expand(5, -1, -1))
     # (layer 0 is the stem conv, which has a fused form of its own: test_fused_stem_depthwise_pointwise_equals_unfused)
-    fused = [i for i in range(3, len(names)) if names[i] == "dwp_kernel" and names[i - 1].startswith("(fused") and names[i - 2].startswith("(fused")]
+    fused = [i for i in range(3, len(names)) if names[i] in ("dwp_kernel", "dwc_kernel") and names[i - 1].startswith("(fused") and names[i - 2].startswith("(fused")]
     assert fused, names
     monkeypatch.setenv("FR_FUSE3", "0")
     m.invalidate()                                   # plans read FR_FUSE3 when they are created
@@ -302,7 +302,37 @@ def test_fused_expand_depthwise_pointwise_equals_unfused(name, prec, golden_x, m
     assert torch.equal(c, b)
     if name != "mobilenetv3_small":                  # (its depthwise layers have 72+ channels: the two-stage form is not taken)
         assert "dwp_kernel" in names2
-    assert not [i for i in range(3, len(names2)) if names2[i] == "dwp_kernel" and names2[i - 2].startswith("(fused")]
+    assert not [i for i in range(3, len(names2)) if names2[i] in ("dwp_kernel", "dwc_kernel") and names2[i - 2].startswith("(fused")]
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f32"])
+@pytest.mark.parametrize("name", ["mobilenetv3_large", "mobilenetv3_small", "mobilenetv2"])
+def test_chunked_expand_depthwise_pointwise_is_bit_identical(name, prec, golden_x, monkeypatch):
+    """dwc_kernel walks the expanded channels of an inverted-residual block in chunks of 32 (expand chunk -> depthwise chunk -> that
+    chunk's two k-steps of the 1x1 conv into register accumulators): same k order and rounding points as dwp_kernel and as the three
+    separate kernels.  Bit for bit: the default plan (chunked on its measured shapes) == FR_DWP_CHUNK=0 (dwp_kernel everywhere) ==
+    FR_DWP_CHUNK=2 (chunked on every eligible shape with the cost model's tiles -- including the 72- and 88-channel blocks whose last
+    chunk holds 1 or 3 of 4 channel vectors, and stride 2) == the unfused plan, at 8 images and at 131 (two-stream split, ragged)."""
+    x = golden_x.to(DEV)
+    m = product(name)
+    big_x = x.repeat(17, 1, 1, 1)[:131]
+    outs = {}
+    for mode in ("1", "0", "2"):
+        monkeypatch.setenv("FR_DWP_CHUNK", mode)
+        m.invalidate()
+        with torch.no_grad():
+            outs[mode] = (m(x, precision=prec, fuse=True), m(big_x, precision=prec, fuse=True))
+        kern = [r[1] for r in m.plan(DEV, prec, True).profile(x)]
+        if mode == "0":
+            assert "dwc_kernel" not in kern, kern
+        elif mode == "2" or not (name == "mobilenetv2" and prec == "f32"):        # (mobilenetv2 f32: no measured win, not in the table)
+            assert "dwc_kernel" in kern, kern
+    with torch.no_grad():
+        unfused = m(x, precision=prec, fuse=False)
+    m.invalidate()
+    for mode in ("1", "0", "2"):
+        assert torch.equal(outs[mode][0], unfused), mode
+        assert torch.equal(outs[mode][1], unfused.repeat(17, 1)[:131]), mode
 
 
 class _StemBlockNet(fr.models.HipBackbone):
