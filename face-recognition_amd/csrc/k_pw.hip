@@ -416,7 +416,14 @@ static int launch_pw_proj_n(const PwArgs& a, hipStream_t st) {
 }
 
 // n-tiles per block: all of them when there are at most 5, else the count in 5, 4, 3 that wastes the fewest tiles
-static int pw_proj_ntc(int NT) {
+static int pw_proj_ntc(int NT, long n_super) {
+    // tuning: FR_PJ_NTC=n splits the n-tiles of a layer with few 128-pixel super-tiles (<= FR_PJ_NTC_SUPER) into column groups of n.
+    // Measured (tools/pj_ntc_sweep.sh, mobilenetv3_large, 512 images): the three 7x7 layers with 160 couts (196 blocks on 256 CUs) as
+    // 3 + 2 tiles: -13 % per layer in bf16, -6 % in f32 alone on the GPU -- and nothing end to end (256.0 vs 256.7 k img/s, f32 128.1 vs
+    // 128.0): the other sub-batch's stream already fills the idle CUs.  On the 14x14 layers (784 blocks) a split costs 30-40 %.  Off.
+    static const int force = getenv("FR_PJ_NTC") ? atoi(getenv("FR_PJ_NTC")) : 0;
+    static const long force_super = getenv("FR_PJ_NTC_SUPER") ? atol(getenv("FR_PJ_NTC_SUPER")) : 256;
+    if (force >= 2 && force <= 4 && NT <= PJ_NT && NT > force && n_super <= force_super) return force;
     if (NT <= PJ_NT) return std::max(NT, 2);
     int best = 5;
     for (int n = 4; n >= 3; --n)
@@ -426,7 +433,7 @@ static int pw_proj_ntc(int NT) {
 
 template <typename T>
 static int launch_pw_proj(const PwArgs& a, hipStream_t st) {
-    switch (pw_proj_ntc(a.NT)) {
+    switch (pw_proj_ntc(a.NT, (a.M + 127) / 128)) {
         case 2: return launch_pw_proj_n<T, 2>(a, st);
         case 3: return launch_pw_proj_n<T, 3>(a, st);
         case 4: return launch_pw_proj_n<T, 4>(a, st);
