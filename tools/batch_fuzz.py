@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import face_recognition_amd as fr
 dev = torch.device("cuda", 0)
 bad = 0
-for name, precs in (("mobilenetv3_large", ("bf16", "f32")), ("mobilenetv2", ("f32",)), ("mobilenetv1", ("bf16",)), ("mobilenetv3_small", ("f32", "f24")), ("sphere20", ("bf16", "f32")), ("sphere36", ("bf16",))):
+for name, precs in (("mobilenetv3_large", ("bf16", "f32")), ("mobilenetv2", ("bf16", "f32")), ("mobilenetv1", ("bf16",)), ("mobilenetv3_small", ("bf16", "f32", "f24")), ("sphere20", ("bf16", "f32")), ("sphere36", ("bf16",))):
     torch.manual_seed(1)
     m = fr.get_network(name).to(dev).eval()
     x = (torch.rand((1000, 3, 112, 112), device=dev) * 2 - 1)
