@@ -569,6 +569,7 @@ struct DwpArgs {
     // STEM form: the layer in front of the depthwise conv is the network's 3x3 stem conv (Cin = 3, stride 1, pad 1) and is
     // computed here from the fp32 NCHW input: K = 27 (padded to 32, k = c*9 + ky*3 + kx as stem_kernel), KSe = 2
     const float* xs;      // network input [N,3,H,W] (H, W = the depthwise input size)
+    int spitch;           // row pitch of the per-wave output staging tiles (bf16 / fp32 plans; f24 keeps the compile-time pitch)
     int off_dwo;          // chunked form (dwc_kernel): LDS byte offset of the depthwise result of one 32-channel chunk
     int off_res;          // > 0: LDS byte offset of the stem output at the tile's own pixels, [TH*TW][C] as stored in HBM
                           // by the unfused plan: the residual of the 1x1 conv (which then never reads one from HBM)
@@ -955,7 +956,9 @@ __global__ __launch_bounds__(256, 2) void dwp_kernel(DwpArgs x, DwGeom g) {
     // 1x1 conv on MFMA: D[cout][pixel] = W . dwo^T, 32 pixels per wave step
     const int p = lane & 31, h = lane >> 5;
     constexpr int SG = STEM ? 1 : 2;     // 32-channel tiles per staged group (stem form: 16..64 couts, and LDS for the patch and the residual)
-    constexpr int PITCH = stage_pitch(SG * 32 * EB);
+    // rows of min(cout, SG * 32) channels: the pitch follows the layer (a 16-cout layer staged at the 64-channel pitch held 18 KB
+    // of LDS per block for 4 KB of data), always an odd number of 16-byte slots; f24 keeps the fixed pitch of its two tiles
+    const int PITCH = F24 ? stage_pitch(SG * 32 * EB) : x.spitch;
     constexpr int PITCH_LO = stage_pitch_lo(SG * 32);
     unsigned char* stage = smem + x.off_stage + wave * 32 * PITCH;
     unsigned char* stage_lo = smem + x.off_stage + 4 * 32 * PITCH + wave * 32 * PITCH_LO;     // f24 only
@@ -1230,6 +1233,14 @@ __global__ __launch_bounds__(256, 2) void dwc_kernel(DwpArgs x, DwGeom g) {
     }
 }
 
+// Row pitch of the output staging tiles of dwp_kernel: min(cout, sg * 32) channels, rounded up to 16 bytes, plus one slot when that makes
+// the slot count odd (b128 rows of 8 consecutive pixels on distinct bank groups), never above the fixed pitch
+static int dwp_stage_pitch(int cout, int sg, int eb) {
+    const int row = ((std::min(cout, sg * 32) * eb + 15) & ~15);
+    const int slots = row / 16 + ((row / 16) % 2 == 0 ? 1 : 0);
+    return std::min(slots * 16, stage_pitch(sg * 32 * eb));
+}
+
 struct DwpPlan { int TH, TW; size_t lds; int off_wp, off_stage, npx_pad, pitch, off_we, off_in, off_pb, off_lo, off_res, off_dwo; bool chunked; };
 
 // Tile for the fused form: all channels in one block, <= 512 work items, everything within 64 KB of LDS
@@ -1294,7 +1305,8 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
     const int CV = C / 8, sw = s == 2 ? 2 : 4;
     const int ns = f32 ? 2 : 1;
     // output staging per block: 4 waves x 32 pixels x 64 channels (f24: a bf16-shaped tile for the hi halves + a byte tile)
-    const size_t stage_bytes = (stem || chunked) ? 4 * 32 * (size_t)stage_pitch(32 * (f32 ? 4 : 2))      // (stem / chunked form: one 32-channel tile per staged group)
+    const size_t stage_bytes = chunked ? 4 * 32 * (size_t)stage_pitch(32 * (f32 ? 4 : 2))      // (chunked form: one 32-channel tile per staged group)
+                             : !f24 ? 4 * 32 * (size_t)dwp_stage_pitch(cout, stem ? 1 : 2, f32 ? 4 : 2)    // (rows of the layer's couts, see dwp_stage_pitch)
                              : 4 * 32 * (f24 ? (size_t)stage_pitch(2 * 32 * 2) + stage_pitch_lo(2 * 32) : (size_t)stage_pitch(2 * 32 * (f32 ? 4 : 2)));
     const size_t in_px_bytes = f24 ? (size_t)cin * 2 + f24_lo_pitch(cin) : (size_t)cin * (f32 ? 4 : 2);   // staged block input per pixel (expand form)
     if (C % 8 || CV > 16 || C > 128 || cout % 8 || cout > 128 || (k != 3 && k != 5) || (s != 1 && s != 2)) return false;
@@ -1465,6 +1477,7 @@ int launch_dwp(int fmt, int k, int stride, DwArgs a, const bf16* wp, const EpiAr
     x.dw = a; x.wp = wp; x.e = e; x.KS = cdiv(a.C, 16); x.NT = cdiv(e.cout, 32);
     x.npx = a.TH * a.TW; x.npx_pad = pl.npx_pad; x.pitch = pl.pitch; x.off_lo = pl.off_lo;
     x.off_wp = pl.off_wp; x.off_stage = pl.off_stage; x.off_pb = pl.off_pb;
+    x.spitch = dwp_stage_pitch(e.cout, (ex && ex->stem) ? 1 : 2, f32 ? 4 : 2);
     if (ex) {
         x.xin = ex->xin; x.xin_lo = ex->xin_lo; x.we = ex->we; x.be = ex->bias; x.se = ex->slope; x.act_e = ex->act; x.Cin = ex->Cin;
         x.KSe = ex->stem ? 2 : cdiv(ex->Cin, 16); x.NTe = cdiv(a.C, 32); x.off_we = pl.off_we; x.off_in = pl.off_in;
