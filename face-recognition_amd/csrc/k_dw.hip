@@ -1256,8 +1256,10 @@ static const DwpTileEntry kDwpTiles[] = {
 // fp32 plans (tools/dwp_probe.py <model> 512 f32; gpurun_out/dwp_probe_b512_*_f32.txt): LDS holds half as many pixels,
 // so the winners are small tiles; shapes not listed use the cost model
 static const DwpTileEntry kDwpTilesF32[] = {
-    {16, 0, 56, 3, 2, 32, 14, 8}, {32, 0, 28, 3, 2, 64, 4, 28}, {32, 0, 112, 3, 1, 16, 16, 16}, {16, 0, 112, 3, 1, 16, 16, 28},
+    {16, 0, 56, 3, 2, 32, 14, 8}, {32, 0, 28, 3, 2, 64, 4, 28}, {32, 0, 112, 3, 1, 16, 16, 16}, {16, 0, 112, 3, 1, 16, 16, 16},
     {64, 16, 56, 3, 2, 24, 4, 8}, {72, 16, 28, 3, 2, 24, 7, 4}, {32, 0, 56, 3, 1, 32, 8, 28},
+    // ({16, 0, 112, ..}: 16 x 16 re-measured after the staging tiles shrank: stem + this layer 0.429 ms vs 0.484 at 16 x 28, and vs 0.480 for
+    // the stem form, which 16-channel plans therefore no longer take)
     // one block per CU (80-150 KB), measured against the best tile under 80 KB:
     {72, 24, 56, 3, 1, 24, 8, 28},        // mobilenetv3_large features.3: 0.372 ms (8 x 8 the same) vs 0.455 at 14 x 8, the winner (0.437 vs 0.603) while the staging tiles had the fixed 64-channel pitch
     {96, 16, 56, 3, 2, 24, 7, 8},         // mobilenetv2 features.2: 0.871 vs 1.10 ms

@@ -434,10 +434,11 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         if (fuse_stem && !with_expand && D.src == i - 1 && i >= 1) {
             Layer& S0 = pl->layers[i - 1];
             const bool res_stem = P.residual == i - 1;
-            // measured per shape (tools/stem_tile_sweep.sh, 512 images, against stem_kernel + dwp_kernel): 32 channels bf16 0.332 vs 0.375 ms,
-            // f32 0.469 vs 0.698; 16 channels f32 0.462 vs 0.490, but bf16 0.323 vs 0.291 -- the stem phase costs a block the same time
-            // whatever the channel count, what it saves grows with the bytes of the stem output: 16-channel bf16 plans keep the two launches
-            const bool pays = af != FMT_BF16 || D.C >= 32;
+            // measured per shape (tools/dwp_tile_check.sh, 512 images, stem + depthwise + 1x1 together, against stem_kernel + dwp_kernel at its
+            // best tile): 32 channels bf16 0.308 vs 0.375 ms, f32 0.486 vs 0.698; 16 channels bf16 0.323 vs 0.270, f32 0.480 vs 0.429 -- the
+            // stem phase costs a block the same time whatever the channel count, what it saves grows with the bytes of the stem output:
+            // 16-channel plans keep the two launches
+            const bool pays = D.C >= 32;
             if (pays && S0.kind == K_STEM && S0.stride == 1 && S0.out_fmt == af && S0.residual < 0 && D.pad == 1 && D.inH == S0.H && D.inW == S0.W &&
                 S0.inH == S0.H && S0.inW == S0.W && (P.residual < 0 || res_stem) && last_use[i - 1] <= i + 1 &&
                 dwp_supported(af, D.k, D.stride, D.C, D.H, D.W, P.cout, res_stem ? DWP_STEM_RES : DWP_STEM)) {
