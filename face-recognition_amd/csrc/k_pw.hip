@@ -908,6 +908,15 @@ static int launch_pw_stream(const PwArgs& a, hipStream_t st) {
     constexpr int SG2 = NTB < 2 ? NTB : 2;
     if constexpr (std::is_same<TOut, bf16>::value)       // (fp32 tiles of 4 n-tiles would take 67 KB of LDS: two at a time, 256-byte runs)
         if (NTB > 2 && a.NT <= NTB) return launch_pw_stream_sg<TIn, TOut, NTB, NTB>(a, st);     // whole rows in one block
+    if constexpr (std::is_same<TOut, float>::value && NTB >= 2) {
+        // fp32 outputs of a layer with two or more column groups (the expansion convs) are staged ONE n-tile (128-byte rows) at a time:
+        // 16 KB less LDS per block -- three blocks per CU beside the hi + lo weight slab instead of two -- for half as long write-back
+        // runs.  Measured per layer (mobilenetv3_large f32, 512 images): 112->672 0.1245 -> 0.105 ms, 80->480 0.073 -> 0.057, 80->200 0.040 ->
+        // 0.032, 40->240 0.1045 -> 0.1016; layers whose block covers whole output rows lose (24->72 at 56x56: 0.120 -> 0.154, 120->40 with
+        // squeeze-excite scale and residual: 0.084 -> 0.089) and keep two n-tiles.  FR_PW_F32_SG1: 0 never, 2 always (sweeps).
+        static const int sg1 = getenv("FR_PW_F32_SG1") ? atoi(getenv("FR_PW_F32_SG1")) : 1;
+        if (sg1 == 2 || (sg1 == 1 && cdiv(a.NT, NTB) >= 2)) return launch_pw_stream_sg<TIn, TOut, NTB, 1>(a, st);
+    }
     return launch_pw_stream_sg<TIn, TOut, NTB, SG2>(a, st);
 }
 
