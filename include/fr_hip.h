@@ -95,7 +95,9 @@ int fr_plan_destroy(fr_plan* plan);
 int fr_plan_workspace_bytes(const fr_plan* plan, int batch, size_t* out_bytes);
 /* Output shape of layer `layer` (c,h,w); LINEAR / SE report (features,1,1). */
 int fr_plan_layer_dims(const fr_plan* plan, int layer, int* c, int* h, int* w);
-/* Number of kernel launches one fr_embed call issues (diagnostics). */
+/* Number of kernel launches one fr_embed call issues per (sub-)batch (diagnostics).  Where a plan computes its 3x3 stem conv inside
+ * the kernel of the first depthwise + 1x1 pair (32-channel stems), fr_embed_u8 and a tap on the stem take one launch more: they run
+ * the stem kernel on its own. */
 int fr_plan_num_launches(const fr_plan* plan);
 
 /* Replaces: `model(tensor)` under torch.no_grad() (inference.py:121-122, evaluate.py:191-192).
