@@ -1340,6 +1340,7 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
     const int tws[] = {4, 8, 16, 28, 32, 56};
     int fth = 0, ftw = 0;                                 // tuning override: FR_DWP_TILE="C,cin,TH,TW" for the matching layers
     if (const char* ov = getenv("FR_DWP_TILE")) { int c0, ci; if (sscanf(ov, "%d,%d,%d,%d", &c0, &ci, &fth, &ftw) != 4 || c0 != C || ci != cin) fth = ftw = 0; }
+    const bool from_env = fth != 0;                       // (a tile from the environment is tried alone; one from a table is a preference)
     if (!fth && cth) { fth = cth; ftw = ctw; }
     // stem form (cin = 3 here): 16 x 16 tiles measured best for 16 and 32 channels in both precisions (tools/stem_tile_sweep.sh, 112 x 112
     // maps, 512 images: mobilenetv3_large bf16 0.323 ms against 0.353..0.51, f32 0.462 against 0.49..0.77; mobilenetv2 0.332 / 0.469)
@@ -1350,6 +1351,10 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
     if (!fth && Ho == Wo && f32 && !chunked)
         for (const DwpTileEntry& e : kDwpTilesF32)
             if (e.C == C && e.cin == cin && e.Ho == Ho && e.k == k && e.s == s && e.cout == cout) { fth = e.TH; ftw = e.TW; break; }
+    // second pass: the table's tile did not fit this format's LDS (f24 plans share the fp32 tables but stage their outputs through two
+    // fixed-pitch tiles): the cost model decides, instead of leaving the layers unfused
+    for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) { if (found || !fth || from_env) break; fth = ftw = 0; }
     for (int th : ths) for (int tw : tws) {
         if (fth && (th != fth || tw != ftw)) continue;
         if (th == 2 && !f32) continue;                    // (2-row tiles: fp32 plans only, where LDS is the limit)
@@ -1405,6 +1410,7 @@ static bool dwp_pick(int fmt, int k, int s, int C, int Ho, int Wo, int cout, int
             best = cost; found = true;
             *out = DwpPlan{th, tw, lds, (int)off_wp, (int)off_stage, npx_pad, pitch, (int)off_we, (int)off_in, (int)off_pb, (int)plane, stem_res ? (int)off_res : 0, 0, false};
         }
+    }
     }
     return found;
 }
