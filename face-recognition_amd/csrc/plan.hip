@@ -6,6 +6,8 @@
 #include <atomic>
 #include <mutex>
 #include <set>
+#include <map>
+#include <array>
 #include <memory>
 #include <vector>
 
@@ -82,16 +84,18 @@ struct fr_plan {
     float* u8_lut = nullptr;              // ((b / 255) - 0.5) / 0.5 for b = 0..255 (fr_embed_u8)
     // fr_embed runs the two halves of a large batch on the caller's stream and on this auxiliary
     // stream (fork/join by events): each half's kernel tails and launch gaps are filled by the other half
+    // The streams are shared by all plans of a device (aux_streams below) and live as long as the process: a GPU process has few
+    // hardware queues (4 here) onto which HIP deals its streams in creation order, and a plan whose own auxiliary stream landed on
+    // the caller's queue ran its two halves one after the other (measured: the third plan of a process 236 k instead of 257 k img/s
+    // in bf16; with GPU_MAX_HW_QUEUES=8 the second one instead).  Events stay per plan.
     static constexpr int MAX_AUX = 3;
     hipStream_t aux[MAX_AUX] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_AUX] = {nullptr, nullptr, nullptr};
     bool act_f32() const { return prec != FR_PREC_BF16; }            // fp32-class arithmetic (FR_PREC_F32 and FR_PREC_F24)
     int act_fmt() const { return prec == FR_PREC_F32 ? FMT_F32 : prec == FR_PREC_F24 ? FMT_F24 : FMT_BF16; }
     ~fr_plan() {
-        for (int i = 0; i < MAX_AUX; ++i) {
-            if (aux[i]) (void)hipStreamDestroy(aux[i]);
+        for (int i = 0; i < MAX_AUX; ++i)
             if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
-        }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (void* p : allocs) (void)hipFree(p);
     }
@@ -359,6 +363,23 @@ size_t layer_out_bytes(const Layer& L) {           // per image
 
 }  // namespace
 
+// The auxiliary streams of a device (created with that device current, on the first plan; never destroyed).  Plans that run
+// concurrently from several host threads share them: their second halves queue behind each other on these streams (ordering only;
+// every plan forks and joins with its own events).
+static int aux_streams(int device, hipStream_t (&out)[fr_plan::MAX_AUX]) {
+    static std::mutex mu;
+    static std::map<int, std::array<hipStream_t, fr_plan::MAX_AUX>> pool;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = pool.find(device);
+    if (it == pool.end()) {
+        std::array<hipStream_t, fr_plan::MAX_AUX> s{};
+        for (int i = 0; i < fr_plan::MAX_AUX; ++i) FR_HIP_CHECK(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
+        it = pool.emplace(device, s).first;
+    }
+    for (int i = 0; i < fr_plan::MAX_AUX; ++i) out[i] = it->second[i];
+    return FR_OK;
+}
+
 extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int in_h, int in_w,
                               int precision, fr_plan** out_plan) {
     if (!descs || n <= 0 || !out_plan || in_c <= 0 || in_h <= 0 || in_w <= 0)
@@ -384,10 +405,12 @@ extern "C" int fr_plan_create(const fr_layer_desc* descs, int n, int in_c, int i
         }
         rc = upload(pl.get(), lut, &pl->u8_lut); if (rc) return rc;
     }
-    for (int i = 0; i < fr_plan::MAX_AUX; ++i) {
-        FR_HIP_CHECK(hipStreamCreateWithFlags(&pl->aux[i], hipStreamNonBlocking));
-        FR_HIP_CHECK(hipEventCreateWithFlags(&pl->ev_join[i], hipEventDisableTiming));
+    {
+        int rc = aux_streams(pl->device, pl->aux);
+        if (rc) return rc;
     }
+    for (int i = 0; i < fr_plan::MAX_AUX; ++i)
+        FR_HIP_CHECK(hipEventCreateWithFlags(&pl->ev_join[i], hipEventDisableTiming));
     FR_HIP_CHECK(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
     pl->layers.reserve(n);
     for (int i = 0; i < n; ++i) {
