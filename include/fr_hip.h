@@ -105,8 +105,9 @@ int fr_plan_num_launches(const fr_plan* plan);
  * [batch,out_features], otherwise the last activation as NCHW fp32.  Raw, un-normalised, as the
  * reference backbones return (utils/layers.py:188-191).
  * Asynchronous on `stream`.  A batch of 128 images or more is cut into two sub-batches, the second of
- * which runs on an auxiliary stream owned by the plan (forked from and joined back to `stream` with
- * events), so one plan serves one host thread at a time; results do not depend on the split.  A workspace must not
+ * which runs on an auxiliary stream of the device, shared by its plans (forked from and joined back to `stream` with
+ * the plan's events), so one plan serves one host thread at a time, and plans used by several threads at once queue their
+ * second halves behind each other on that stream; results do not depend on the split.  A workspace must not
  * be shared by calls that can overlap on the GPU: calls enqueued on different streams need different workspaces
  * (the host layer keeps one per plan, device and stream). */
 int fr_embed(const fr_plan* plan, const float* x, int batch, float* out,
